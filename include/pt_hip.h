@@ -1,0 +1,201 @@
+/*
+ * pt_hip.h -- C ABI of the MI355X rendering backend (libpt_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of LinzhouLi/Path-Tracer: BVH closest-hit and any-hit traversal,
+ * the ray-triangle test and the MIS path-tracing integrator loop.  Plain C types only; no exceptions cross it.
+ * Every function returns 0 on success and a negative pt_status on failure; pt_hip_last_error() gives the message
+ * (thread-local), which a C++ host rethrows as the reference's PathTracerException (include/pt/common.h:75-80).
+ *
+ * One process drives one GPU (pt_hip_init selects it); multi-GPU rendering is N processes that each render a
+ * disjoint sample range into their own film and sum the films with one reduce.
+ *
+ * The handle is not thread-safe: call from one host thread, as the reference's render thread does (src/main.cpp:185).
+ *
+ * File:line citations are relative to the reference repository root.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_HIP_ABI_VERSION 1
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,   /* bad argument / scene description fails validation */
+    PT_ERR_DEVICE = -2,    /* HIP runtime error (message carries the HIP error string) */
+    PT_ERR_NOT_INIT = -3,  /* pt_hip_init has not been called */
+    PT_ERR_LIMIT = -4      /* scene exceeds a documented limit (BVH depth, triangle count) */
+} pt_status;
+
+/* ---- flat scene description (host memory, read-only during pt_hip_scene_create, not retained) -------------------- */
+
+/* Binary BVH node exactly as the reference builds it (include/pt/bvh.h:13-45), with 32-bit indices.
+ * Interior: count == 0, children are nodes first and first+1.  Leaf: count in [1,8], first indexes prim_ids. */
+typedef struct pt_bvh_node {
+    float    lo[3];
+    float    hi[3];
+    uint32_t first;
+    uint32_t count;
+} pt_bvh_node;
+
+/* Phong material (include/pt/material.h:17-62): Kd, Ks, Ns, optional diffuse texture (-1 = none). */
+typedef struct pt_material {
+    float   kd[3];
+    float   ks[3];
+    float   ns;
+    int32_t tex;
+} pt_material;
+
+/* One area light per emissive triangle, in the reference's order: XML <light> order outer, triangle order inner
+ * (src/scene.cpp:251-260).  area = Triangle::surfaceArea() (src/shape.cpp:32-36). */
+typedef struct pt_light {
+    uint32_t tri;
+    float    lemit[3];
+    float    area;
+} pt_light;
+
+/* Linear-RGB float texture, row-major h x w x 3 (src/bitmap.cpp:68-93). */
+typedef struct pt_texture {
+    uint32_t     w, h;
+    const float* rgb;
+} pt_texture;
+
+/* Camera after the constructor of src/camera.cpp:46-80 has run.  Matrices are row-major 4x4. */
+typedef struct pt_camera {
+    uint32_t width, height;
+    float    eye[3];
+    float    sample2camera[16];
+    float    camera2world[16];
+    float    proj_nume;
+} pt_camera;
+
+typedef struct pt_scene_desc {
+    uint32_t n_verts, n_normals, n_uvs, n_tris, n_mats, n_lights, n_textures, n_nodes;
+    const float*       verts;    /* 3 per vertex */
+    const float*       normals;  /* 3 per normal (may be NULL when n_normals == 0) */
+    const float*       uvs;      /* 2 per uv     (may be NULL when n_uvs == 0) */
+    const uint32_t*    vi;       /* 3 per triangle, 1-based (include/pt/mesh.h:31-35) */
+    const uint32_t*    ni;       /* 3 per triangle, 1-based, 0 = absent (mesh.h:37-44) */
+    const uint32_t*    ti;       /* 3 per triangle, 1-based, 0 = absent (mesh.h:46-53) */
+    const uint32_t*    mat_id;   /* 1 per triangle */
+    const int32_t*     light_id; /* 1 per triangle, -1 = not an emitter */
+    const pt_material* mats;
+    const pt_light*    lights;
+    const pt_texture*  textures;
+    pt_camera          camera;
+    const pt_bvh_node* nodes;    /* n_nodes, root = 0 */
+    const uint32_t*    prim_ids; /* n_tris: leaf order -> triangle index (BVHTree::m_prim_ids) */
+} pt_scene_desc;
+
+/* ---- rays and hits ------------------------------------------------------------------------------------------------ */
+
+/* include/pt/ray.h:7-27 without the unused reciprocal direction. */
+typedef struct pt_ray {
+    float org[3];
+    float dir[3];
+    float tmin;
+    float tmax;
+} pt_ray;
+
+/* Closest hit.  prim = triangle index or -1; barycentrics are (1-u-v, u, v) as in src/shape.cpp:86. */
+typedef struct pt_hit {
+    int32_t prim;
+    float   t;
+    float   u;
+    float   v;
+} pt_hit;
+
+/* Traversal modes.
+ * EXACT replays the reference's visit order on the binary tree (src/bvh.cpp:26-86): pop, cull interior nodes with the
+ * current max distance, never box-test leaves, accept t <= max, last accepted wins.
+ * FAST is an ordered traversal of a 2-wide node layout built from the same tree and the same boxes; rays that see two
+ * triangles at the same distance are re-traced in EXACT mode so that the reported triangle is the reference's. */
+enum { PT_TRAVERSE_EXACT = 0, PT_TRAVERSE_FAST = 1 };
+
+/* Integrators (src/integrator.cpp): MIS path tracer :45-141, shading normal :20-31, base colour :33-43. */
+enum { PT_INTEGRATOR_PATH = 0, PT_INTEGRATOR_NORMAL = 1, PT_INTEGRATOR_ALBEDO = 2 };
+
+typedef struct pt_render_params {
+    uint32_t spp_begin;        /* first Sobol' sample index (inclusive) */
+    uint32_t spp_end;          /* last sample index (exclusive) */
+    uint32_t max_bounce;       /* 32 in the reference (src/integrator.cpp:50); 0 selects 32 */
+    int32_t  integrator;       /* PT_INTEGRATOR_* */
+    int32_t  traversal;        /* PT_TRAVERSE_* */
+    uint32_t samples_per_pass; /* samples of every pixel in flight at once; 0 = choose from free memory */
+    uint32_t reserved[2];
+} pt_render_params;
+
+#define PT_MAX_KERNEL_STATS 8
+typedef struct pt_stats {
+    uint64_t paths;           /* camera paths started */
+    uint64_t closest_rays;    /* closest-hit queries (Scene::rayIntersect(ray, its)) */
+    uint64_t any_rays;        /* any-hit queries (Scene::unocculded) */
+    uint64_t exact_retraces;  /* FAST-mode rays re-traced in EXACT mode */
+    double   seconds;         /* wall time of the call, device work included */
+    /* per-kernel device time (HIP events on the launch stream) and launch counts */
+    double   kernel_ms[PT_MAX_KERNEL_STATS];
+    uint64_t kernel_launches[PT_MAX_KERNEL_STATS];
+} pt_stats;
+enum { PT_K_GENERATE = 0, PT_K_EXTEND = 1, PT_K_SHADE = 2, PT_K_SHADOW = 3, PT_K_FILM = 4, PT_K_RETRACE = 5 };
+
+typedef struct pt_hip_scene pt_hip_scene;
+
+/* ---- life cycle --------------------------------------------------------------------------------------------------- */
+
+/* Selects the GPU this process drives and creates its stream.  No counterpart in the reference (CPU only). */
+int pt_hip_init(int device_ordinal);
+int pt_hip_shutdown(void);
+const char* pt_hip_last_error(void);
+int pt_hip_abi_version(void);
+
+/* Replaces Scene::preprocess's accelerator hand-off, `m_accel = new BVHTree(&m_shapes); m_accel->build()`
+ * (src/scene.cpp:231-232): validates the description, flattens the host-built BVH into the device layouts and
+ * uploads mesh, materials, lights, camera and the Sobol' tables. */
+int pt_hip_scene_create(const pt_scene_desc* desc, pt_hip_scene** out);
+/* Replaces `delete m_accel` in Scene::~Scene (include/pt/scene.h:18-26): frees device copies only. */
+int pt_hip_scene_destroy(pt_hip_scene* scene);
+
+/* ---- batched ray queries (the Accel interface, include/pt/accel.h:10-24) ------------------------------------------ */
+
+/* Accel::rayIntersect(const Ray&, Intersection&) -> BVHTree::rayIntersect (src/bvh.cpp:26-59), n rays at once.
+ * Host pointers; copies in, traces, copies out. */
+int pt_hip_intersect(pt_hip_scene* scene, const pt_ray* rays, size_t n, pt_hit* hits, int mode);
+/* Accel::rayIntersect(const Ray&) -> BVHTree::rayIntersect (src/bvh.cpp:61-86).  occluded[i] = 1 when any triangle is
+ * hit.  first_prim (nullable) receives the first triangle found in the reference's order, -1 if none; it is only
+ * defined in EXACT mode (FAST mode writes -2 for occluded rays). */
+int pt_hip_occluded(pt_hip_scene* scene, const pt_ray* rays, size_t n, uint8_t* occluded, int32_t* first_prim, int mode);
+/* Same two queries on device-resident buffers (no copies; used for throughput measurement).  Synchronous. */
+int pt_hip_intersect_device(pt_hip_scene* scene, const pt_ray* d_rays, size_t n, pt_hit* d_hits, int mode, float* kernel_ms);
+int pt_hip_occluded_device(pt_hip_scene* scene, const pt_ray* d_rays, size_t n, uint8_t* d_occluded, int mode, float* kernel_ms);
+
+/* ---- rendering (the Integrator interface + frame loop) ------------------------------------------------------------- */
+
+/* Replaces render(scene, sampler, integrator, result) (src/main.cpp:76-98) for samples [spp_begin, spp_end) of every
+ * pixel with a SobolSampler (src/sampler.cpp:89-123).  film_rgba is (height+4) x (width+4) x 4 floats, row-major, the
+ * layout of the reference's ImageBlock with its 2-pixel border (include/pt/block.h:35, src/block.cpp:14-35); it is
+ * overwritten (not accumulated into).  Host pointer. */
+int pt_hip_render(pt_hip_scene* scene, const pt_render_params* params, float* film_rgba, pt_stats* stats);
+/* Same with the film in device memory (for a device-side reduce across processes). */
+int pt_hip_render_device(pt_hip_scene* scene, const pt_render_params* params, float* d_film_rgba, pt_stats* stats);
+
+/* Integrator::Li (include/pt/integrator.h:9-19) for an explicit list of (pixel, sample index) pairs: writes the
+ * radiance of each sample (3 floats) and its film position (2 floats, nullable) without touching a film.
+ * pixel_xy holds n (x, y) pairs. */
+int pt_hip_li(pt_hip_scene* scene, const pt_render_params* params, const int32_t* pixel_xy, const uint32_t* sample_index,
+              size_t n, float* rgb, float* pixel_sample, pt_stats* stats);
+
+/* SobolSampler::sampleDimension after startPixelSample (src/sampler.cpp:96-100, include/pt/sampler.h:122):
+ * value of dimension dim[i] for pixel (x,y)[i] and sample index sample_index[i]. */
+int pt_hip_sobol(pt_hip_scene* scene, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim, size_t n,
+                 float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_HIP_H */

@@ -1,0 +1,412 @@
+// Wavefront path-tracing kernels (generate+extend, extend, shade, shadow, film) and the batched ray-query kernels.
+//
+// One render pass keeps `spp_pass` samples of every pixel in flight.  A sample owns a fixed SLOT:
+//     slot = ((tile * spp_pass + s) * 64 + lane),  tile = 8x8 pixels, lane = y_in_tile * 8 + x_in_tile
+// so that a wave starts as one 8x8 pixel tile of one sample number (coherent primary rays, a wave-uniform Sobol' row).
+// Radiance is accumulated per slot in `lbuf` in the reference's order (emission, then direct light, bounce by bounce:
+// src/integrator.cpp:58-73).  Path state travels with the compacted queues: every kernel reads and writes lane-
+// contiguous float4 streams, and a path's position in the queue changes from bounce to bounce while its slot does not.
+#pragma once
+
+#include "shade.h"
+#include "traverse.h"
+
+namespace ptd {
+
+struct PathQ {
+    float4* a;       // {o.x, o.y, o.z, d.x}
+    float4* b;       // {d.y, d.z, T.x, T.y}
+    float4* c;       // {T.z, brdfPdf, bits(px | py << 16), bits(dim | bounce << 10 | frame << 16)}
+    uint32_t* slot;  // sample slot
+    float4* hit;     // {bits(prim), t, u, v} written by the extend step
+};
+
+struct ShadowQ {
+    float4* a;  // {o.x, o.y, o.z, d.x}
+    float4* b;  // {d.y, d.z, tmax, bits(slot)}
+    float4* c;  // {contribution rgb (throughput already applied), 0}
+};
+
+struct PassArgs {
+    const uint32_t* frame_tab;  // [frame_local][1024] Sobol' words of the sample numbers of this pass
+    uint32_t spp_pass;          // samples per pixel in this pass
+    uint32_t tiles_x, tiles_y;
+    uint32_t n_slots;
+    int32_t integrator;
+    int32_t traversal;
+    uint32_t max_bounce;
+    // list mode (pt_hip_li): explicit (pixel, frame_local) pairs instead of the tile mapping
+    const int32_t* list_xy;
+    const uint32_t* list_frame;
+    float* list_pixel_sample;
+};
+
+// counters[0] = entries in the next path queue, [1] = entries in the shadow queue, [2] = exact re-traces
+struct Counters {
+    uint32_t* v;
+};
+
+PTD uint32_t lane_id() { return __lane_id(); }
+
+// Wave-level queue allocation: one atomic per wave, ballot + prefix popcount for the lane offset.
+PTD uint32_t wave_alloc(bool want, uint32_t* counter) {
+    const uint64_t mask = __ballot(want);
+    const uint32_t total = uint32_t(__popcll(mask));
+    uint32_t base = 0;
+    if (total != 0u) {
+        const int leader = __ffsll((unsigned long long)mask) - 1;
+        if (int(lane_id()) == leader) base = atomicAdd(counter, total);
+        base = uint32_t(__shfl(int(base), leader));
+    }
+    return base + uint32_t(__popcll(mask & ((1ull << lane_id()) - 1ull)));
+}
+
+PTD bool trace_closest(const DevScene& sc, int traversal, const RayD& ray, HitD& hit, uint32_t* lds, uint32_t* retrace_counter) {
+    if (traversal == 0) return closest_exact(sc, ray, hit, lds);
+    bool tie;
+    bool found = closest_fast(sc, ray, hit, tie, lds);
+    if (tie) {  // two triangles at the same distance: let the reference's visit order decide
+        found = closest_exact(sc, ray, hit, lds);
+        if (retrace_counter) atomicAdd(retrace_counter, 1u);
+    }
+    return found;
+}
+
+PTD bool trace_any(const DevScene& sc, int traversal, const RayD& ray, uint32_t* lds) {
+    if (traversal == 0) {
+        int32_t fp;
+        return any_exact(sc, ray, fp, lds);
+    }
+    return any_fast(sc, ray, lds);
+}
+
+// ------------------------------------------------------------------------------------------------ batched queries
+
+__global__ __launch_bounds__(kBlock) void k_intersect(DevScene sc, const float4* rays, uint32_t n, float4* hits, int mode,
+                                                       uint32_t* retrace_counter) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
+    const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
+    HitD h;
+    trace_closest(sc, mode, ray, h, s_stack + threadIdx.x, retrace_counter);
+    hits[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+}
+
+__global__ __launch_bounds__(kBlock) void k_occluded(DevScene sc, const float4* rays, uint32_t n, uint8_t* occ, int32_t* first_prim,
+                                                      int mode) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
+    const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
+    bool hit;
+    int32_t fp = -2;
+    if (mode == 0)
+        hit = any_exact(sc, ray, fp, s_stack + threadIdx.x);
+    else
+        hit = any_fast(sc, ray, s_stack + threadIdx.x);
+    occ[i] = hit ? 1 : 0;
+    if (first_prim) first_prim[i] = hit ? fp : -1;
+}
+
+// ------------------------------------------------------------------------------------------------ generate + first extend
+
+// renderBlock's per-sample prologue (src/main.cpp:63-68): startPixelSample, pixelSample = pixel + samplePixel2D(),
+// then the camera ray and the first Scene::rayIntersect of PathIntegrator::Li (src/integrator.cpp:46-53).
+// For the two AOV integrators (src/integrator.cpp:20-43) the result is final and goes straight to lbuf.
+__global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, PathQ q, float4* lbuf, Counters cnt) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    bool valid = slot < pa.n_slots;
+    uint32_t px = 0, py = 0, frame = 0;
+    if (valid) {
+        if (pa.list_xy) {
+            px = uint32_t(pa.list_xy[2 * size_t(slot)]);
+            py = uint32_t(pa.list_xy[2 * size_t(slot) + 1]);
+            frame = pa.list_frame[slot];
+        } else {
+            const uint32_t lane = slot & 63u, ws = slot >> 6;
+            frame = ws % pa.spp_pass;
+            const uint32_t tile = ws / pa.spp_pass;
+            px = (tile % pa.tiles_x) * 8u + (lane & 7u);
+            py = (tile / pa.tiles_x) * 8u + (lane >> 3);
+        }
+        valid = px < sc.cam.width && py < sc.cam.height;
+    }
+    bool alive = false;
+    HitD h{-1, 0.0f, 0.0f, 0.0f};
+    RayD ray{};
+    if (valid) {
+        Sampler smp;
+        smp.start(sc, pa.frame_tab + size_t(frame) * 1024u, px, py, 2);
+        const V2 j = smp.pixel2();
+        const V2 ps{float(int(px)) + j.x, float(int(py)) + j.y};
+        if (pa.list_pixel_sample) {
+            pa.list_pixel_sample[2 * size_t(slot)] = ps.x;
+            pa.list_pixel_sample[2 * size_t(slot) + 1] = ps.y;
+        }
+        camera_ray(sc.cam, ps, ray.o, ray.d, ray.tmin, ray.tmax);
+        alive = trace_closest(sc, pa.traversal, ray, h, s_stack + threadIdx.x, cnt.v + 2);
+        V3 out = mk3(0.0f);
+        if (alive && pa.integrator != 0) {
+            Surf it;
+            complete(sc, uint32_t(h.prim), h.u, h.v, it);
+            out = (pa.integrator == 1) ? it.n : base_color(sc, load_mat(sc, it.prim), it.uv);
+            alive = false;
+        }
+        lbuf[slot] = make_float4(out.x, out.y, out.z, 0.0f);
+    } else if (slot < pa.n_slots) {
+        lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    const uint32_t dst = wave_alloc(alive, cnt.v + 0);
+    if (alive) {
+        q.a[dst] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
+        q.b[dst] = make_float4(ray.d.y, ray.d.z, 1.0f, 1.0f);
+        q.c[dst] = make_float4(1.0f, 0.0f, as_f(px | (py << 16)), as_f(2u | (0u << 10) | (frame << 16)));
+        q.slot[dst] = slot;
+        q.hit[dst] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ extend (bounce >= 1)
+
+// Scene::rayIntersect for rays spawned by Intersection::genRay (src/shape.cpp:186-189): tmin 0, tmax +inf.
+__global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathQ q, uint32_t n, int traversal, Counters cnt) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = q.a[i], b = q.b[i];
+    const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
+    HitD h;
+    trace_closest(sc, traversal, ray, h, s_stack + threadIdx.x, cnt.v + 2);
+    q.hit[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+}
+
+// ------------------------------------------------------------------------------------------------ shade
+
+// One iteration of the loop body of PathIntegrator::Li after the intersection (src/integrator.cpp:55-103) plus
+// sampleLd up to the visibility test (src/integrator.cpp:109-141): the shadow ray and its already-weighted
+// contribution go to the shadow queue, the continued path to the next path queue.
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, PathQ in, uint32_t n, PathQ out, ShadowQ sh, float4* lbuf,
+                                                Counters cnt) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool cont = false, want_shadow = false;
+    float4 na{}, nb{}, nc{}, sa{}, sb{}, sc4{};
+    uint32_t slot = 0;
+    if (i < n) {
+        const float4 hit = in.hit[i];
+        const int32_t prim = int32_t(as_u(hit.x));
+        if (prim >= 0) {  // a miss ends the path (src/integrator.cpp:53)
+            const float4 a = in.a[i], b = in.b[i], c = in.c[i];
+            slot = in.slot[i];
+            const V3 ro{a.x, a.y, a.z}, rd{a.w, b.x, b.y};
+            V3 T{b.z, b.w, c.x};
+            const float brdfPdf = c.y;
+            const uint32_t pix = as_u(c.z), meta = as_u(c.w);
+            const uint32_t frame = meta >> 16;
+            int bounce = int((meta >> 10) & 63u);
+            Sampler smp;
+            smp.start(sc, pa.frame_tab + size_t(frame) * 1024u, pix & 0xffffu, pix >> 16, int(meta & 1023u));
+
+            Surf it;
+            complete(sc, uint32_t(prim), hit.z, hit.w, it);
+            const V3 wo = -rd;
+            const Mat m = load_mat(sc, it.prim);
+            const V3 kd = base_color(sc, m, it.uv);
+
+            // emitted radiance with MIS against light sampling (src/integrator.cpp:58-69)
+            const int32_t lid = sc.light_id[it.prim];
+            if (lid >= 0) {
+                const DevLight& l = sc.lights[lid];
+                const V3 Le = dot(it.n, wo) > 0.0f ? V3{l.lemit[0], l.lemit[1], l.lemit[2]} : mk3(0.0f);
+                V3 add;
+                if (bounce == 0) {
+                    add = cmul(T, Le);
+                } else {
+                    float lpdf = light_pdf(l, it.p, it.n, ro, rd);
+                    lpdf *= 1.0f / float(sc.n_lights);
+                    const float w = power_heuristic(brdfPdf, lpdf);
+                    add = w * cmul(T, Le);
+                }
+                float4 L = lbuf[slot];
+                L.x += add.x;
+                L.y += add.y;
+                L.z += add.z;
+                lbuf[slot] = L;
+            }
+
+            // light sampling (src/integrator.cpp:109-141)
+            if (sc.n_lights != 0u) {
+                const float u1 = smp.s1();
+                uint32_t li = uint32_t(int(u1 * float(sc.n_lights)));  // include/pt/light.h:58-60
+                if (li >= sc.n_lights) li = sc.n_lights - 1u;          // the reference would throw here; clamp instead
+                const DevLight& l = sc.lights[li];
+                const float selectPdf = 1.0f / float(sc.n_lights);
+                const LiSample ls = light_sample(sc, l, it.p, it.n, smp.s2());
+                if (ls.pdfDir != 0.0f) {
+                    // Scene::unocculded (src/scene.cpp:213-220)
+                    const V3 p0 = it.p + it.n * kEps, p1 = ls.p + ls.n * kEps;
+                    const V3 d = p1 - p0;
+                    const float dist = norm(d);
+                    const V3 sd = d / dist;
+                    const V3 f = brdf_eval(m, kd, it.n, wo, ls.wi);
+                    const float cosTheta = dot(it.n, ls.wi);
+                    const float bp = brdf_pdf(m, kd, it.n, wo, ls.wi);
+                    const float lp = ls.pdfDir * selectPdf;
+                    const float w = power_heuristic(lp, bp);
+                    const V3 Ld = w * cmul(f, ls.L) * cosTheta / lp;
+                    const V3 contrib = cmul(T, Ld);
+                    want_shadow = true;
+                    sa = make_float4(p0.x, p0.y, p0.z, sd.x);
+                    sb = make_float4(sd.y, sd.z, dist * (1 - kEps), as_f(slot));
+                    sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+                }
+            }
+
+            // BRDF sampling; the 2-D sample is drawn before the 1-D one (src/integrator.cpp:83, right-to-left arguments)
+            const V2 u = smp.s2();
+            const float uc = smp.s1();
+            const BSample bs = brdf_sample(m, kd, it, wo, uc, u);
+            float newPdf = brdfPdf;
+            bool go = true;
+            if (bs.specular) {
+                bounce--;
+                newPdf = 1.0f;
+            } else {
+                if (sqnorm(bs.f) == 0.0f || bs.pdf == 0.0f) go = false;
+                if (go) {
+                    const V3 thr = bs.f * dot(it.n, bs.wi) / bs.pdf;
+                    T = cmul(T, thr);
+                    newPdf = bs.pdf;
+                }
+            }
+            if (go) {
+                const V3 no = it.p + it.ng * kEps;  // Intersection::genRay (src/shape.cpp:186-189)
+                // Russian roulette (src/integrator.cpp:99-103)
+                if (maxc(T) < 1.0f && bounce > 1) {
+                    const float qq = std_max(0.0f, 1.0f - maxc(T));
+                    if (smp.s1() < qq) go = false;
+                    T = T / (1.0f - qq);
+                }
+                bounce++;
+                if (go && bounce < int(pa.max_bounce)) {
+                    cont = true;
+                    na = make_float4(no.x, no.y, no.z, bs.wi.x);
+                    nb = make_float4(bs.wi.y, bs.wi.z, T.x, T.y);
+                    nc = make_float4(T.z, newPdf, as_f(pix), as_f(uint32_t(smp.dim) | (uint32_t(bounce) << 10) | (frame << 16)));
+                }
+            }
+        }
+    }
+    const uint32_t sdst = wave_alloc(want_shadow, cnt.v + 1);
+    if (want_shadow) {
+        sh.a[sdst] = sa;
+        sh.b[sdst] = sb;
+        sh.c[sdst] = sc4;
+    }
+    const uint32_t dst = wave_alloc(cont, cnt.v + 0);
+    if (cont) {
+        out.a[dst] = na;
+        out.b[dst] = nb;
+        out.c[dst] = nc;
+        out.slot[dst] = slot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ shadow
+
+// Visibility test of sampleLd (src/integrator.cpp:124-126): unoccluded rays add their contribution.
+__global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, ShadowQ sh, uint32_t n, int traversal, float4* lbuf) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = sh.a[i], b = sh.b[i];
+    const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
+    if (!trace_any(sc, traversal, ray, s_stack + threadIdx.x)) {
+        const float4 c = sh.c[i];
+        const uint32_t slot = as_u(b.w);
+        float4 L = lbuf[slot];
+        L.x += c.x;
+        L.y += c.y;
+        L.z += c.z;
+        lbuf[slot] = L;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ film
+
+// ImageBlock::put for the whole-image block (src/block.cpp:60-95): every sample is splatted with the tabulated
+// Gaussian over [ceil(p-2), floor(p+2)]^2 around its film position p = pixelSample + border.  One workgroup owns a
+// 16x16 pixel region (2x2 tiles), accumulates its samples into a 20x20 RGBA patch in LDS and adds the patch to the
+// film once.
+__global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const float4* lbuf, float* film) {
+    __shared__ float s_patch[20 * 20 * 4];
+    for (int k = threadIdx.x; k < 20 * 20 * 4; k += 256) s_patch[k] = 0.0f;
+    __syncthreads();
+    const uint32_t regions_x = (pa.tiles_x + 1u) / 2u;
+    const uint32_t rx = blockIdx.x % regions_x, ry = blockIdx.x / regions_x;
+    const uint32_t sub = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t tx = 2u * rx + (sub & 1u), ty = 2u * ry + (sub >> 1);
+    const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
+    if (tx < pa.tiles_x && ty < pa.tiles_y && px < sc.cam.width && py < sc.cam.height) {
+        const uint32_t tile = ty * pa.tiles_x + tx;
+        for (uint32_t s = 0; s < pa.spp_pass; ++s) {
+            const uint32_t slot = ((tile * pa.spp_pass + s) << 6) + lane;
+            const float4 L = lbuf[slot];
+            Sampler smp;
+            smp.start(sc, pa.frame_tab + size_t(s) * 1024u, px, py, 2);
+            const V2 j = smp.pixel2();
+            // film coordinates (border included), relative to the patch origin
+            const float lx = (float(int(px)) + j.x) + 2.0f, ly = (float(int(py)) + j.y) + 2.0f;
+            const int x0 = int(ceilf(lx - 2.0f)), x1 = int(floorf(lx + 2.0f));
+            const int y0 = int(ceilf(ly - 2.0f)), y1 = int(floorf(ly + 2.0f));
+            float wx[5], wy[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                wx[k] = sc.filter[min(int(fabsf(float(x0 + k) - lx) * 16.0f), 32)];
+                wy[k] = sc.filter[min(int(fabsf(float(y0 + k) - ly) * 16.0f), 32)];
+            }
+            const int ox = x0 - int(16u * rx), oy = y0 - int(16u * ry);
+#pragma unroll
+            for (int yy = 0; yy < 5; ++yy) {
+                if (y0 + yy > y1) break;
+#pragma unroll
+                for (int xx = 0; xx < 5; ++xx) {
+                    if (x0 + xx > x1) break;
+                    float* p = s_patch + ((oy + yy) * 20 + (ox + xx)) * 4;
+                    atomicAdd(p + 0, L.x * wx[xx] * wy[yy]);
+                    atomicAdd(p + 1, L.y * wx[xx] * wy[yy]);
+                    atomicAdd(p + 2, L.z * wx[xx] * wy[yy]);
+                    atomicAdd(p + 3, 1.0f * wx[xx] * wy[yy]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int fw = int(sc.cam.width) + 4, fh = int(sc.cam.height) + 4;
+    for (int k = threadIdx.x; k < 20 * 20; k += 256) {
+        const int fx = int(16u * rx) + k % 20, fy = int(16u * ry) + k / 20;
+        if (fx < fw && fy < fh && s_patch[4 * k + 3] != 0.0f) {
+            float* dst = film + (size_t(fy) * fw + fx) * 4;
+            atomicAdd(dst + 0, s_patch[4 * k + 0]);
+            atomicAdd(dst + 1, s_patch[4 * k + 1]);
+            atomicAdd(dst + 2, s_patch[4 * k + 2]);
+            atomicAdd(dst + 3, s_patch[4 * k + 3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sampler probe
+
+__global__ void k_sobol(DevScene sc, const uint32_t* frame_tab, const int32_t* xy, const uint32_t* frame_local, const uint32_t* dim,
+                        uint32_t n, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Sampler smp;
+    smp.start(sc, frame_tab + size_t(frame_local[i]) * 1024u, uint32_t(xy[2 * size_t(i)]), uint32_t(xy[2 * size_t(i) + 1]), 2);
+    out[i] = smp.value(int(dim[i]));
+}
+
+}  // namespace ptd

@@ -1,0 +1,816 @@
+// libpt_hip.so: C ABI (include/pt_hip.h) over the HIP kernels in kernels.h.
+//
+// Host-side responsibilities: validate the flat scene description, flatten the host-built binary BVH into the two
+// device layouts (reference-order nodes and the ordered 2-wide nodes), build the Sobol' look-up tables, own the
+// per-pass work buffers, and drive the wavefront loop (generate -> [shade -> shadow + extend]* -> film).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "pt_hip.h"
+#include "sobol_tables.inc"
+
+using namespace ptd;
+
+namespace {
+
+thread_local std::string g_error;
+int g_device = -1;
+hipStream_t g_stream = nullptr;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                                           std::to_string(__LINE__) + ")");                                    \
+    } while (0)
+
+// ---- Sobol' helpers (host) ----------------------------------------------------------------------------------------
+
+inline uint32_t sobol_word(uint64_t index, int dim) {  // the XOR part of sobolSample (src/sampler.cpp:6-14)
+    uint32_t v = 0;
+    for (int i = dim * 52; index != 0; index >>= 1, ++i)
+        if (index & 1) v ^= kSobolMatrices32[i];
+    return v;
+}
+inline int32_t round_up_pow2(int32_t v) {  // src/sampler.cpp:68-76
+    v--;
+    v |= v >> 1;
+    v |= v >> 2;
+    v |= v >> 4;
+    v |= v >> 8;
+    v |= v >> 16;
+    return v + 1;
+}
+// index bits contributed by the sample number alone (sobolIntervalToIndex with pixel (0,0), src/sampler.cpp:16-36)
+inline uint64_t frame_index(uint32_t m, uint64_t frame) {
+    if (m == 0) return frame;
+    uint64_t index = frame << (2 * m);
+    uint64_t delta = 0;
+    for (int c = 0; frame; frame >>= 1, ++c)
+        if (frame & 1) delta ^= kVdCSobolMatrices[m - 1][c];
+    for (int c = 0; delta; delta >>= 1, ++c)
+        if (delta & 1) index ^= kVdCSobolMatricesInv[m - 1][c];
+    return index;
+}
+
+struct Workspace {
+    uint32_t cap_slots = 0;
+    PathQ q[2]{};
+    ShadowQ sh{};
+    float4* lbuf = nullptr;
+    uint32_t* counters = nullptr;  // device, 4 words
+    uint32_t* h_counters = nullptr;  // pinned host mirror
+    uint32_t* frame_tab = nullptr;
+    size_t frame_cap = 0;  // in frames
+    std::vector<void*> owned;
+};
+
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    std::vector<int> kind;  // kernel id of pair i (events 2i, 2i+1)
+    size_t used = 0;
+};
+
+}  // namespace
+
+struct pt_hip_scene {
+    DevScene dev{};
+    std::vector<void*> owned;
+    uint32_t sob_m = 0;
+    uint32_t depth = 0;
+    uint32_t width = 0, height = 0;
+    Workspace ws;
+    EventPool events;
+};
+
+namespace {
+
+template <typename T>
+int upload(pt_hip_scene* s, const T* src, size_t count, const T** dst) {
+    void* d = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&d, bytes));
+    s->owned.push_back(d);
+    if (count) HIP_TRY(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T*>(d);
+    return PT_OK;
+}
+
+int validate(const pt_scene_desc* d, uint32_t& depth_out) {
+    if (!d) return fail(PT_ERR_INVALID, "scene description is null");
+    if (d->n_tris == 0 || d->n_nodes == 0) return fail(PT_ERR_INVALID, "scene has no triangles or no BVH nodes");
+    if (!d->verts || !d->vi || !d->mat_id || !d->light_id || !d->mats || !d->nodes || !d->prim_ids)
+        return fail(PT_ERR_INVALID, "scene description has a null required array");
+    if (d->n_tris > kLeafFirstMask) return fail(PT_ERR_LIMIT, "more than 2^27-1 triangles");
+    if (d->camera.width == 0 || d->camera.height == 0 || d->camera.width > 32768 || d->camera.height > 32768)
+        return fail(PT_ERR_INVALID, "camera resolution out of range (1..32768)");
+    for (size_t i = 0; i < 3 * size_t(d->n_tris); ++i) {
+        if (d->vi[i] == 0 || d->vi[i] > d->n_verts) return fail(PT_ERR_INVALID, "vertex index out of range");
+        if (d->n_normals && d->ni && d->ni[i] > d->n_normals) return fail(PT_ERR_INVALID, "normal index out of range");
+        if (d->n_uvs && d->ti && d->ti[i] > d->n_uvs) return fail(PT_ERR_INVALID, "uv index out of range");
+    }
+    if ((d->n_normals && !d->ni) || (d->n_uvs && !d->ti)) return fail(PT_ERR_INVALID, "normals/uvs given without index arrays");
+    for (uint32_t t = 0; t < d->n_tris; ++t) {
+        if (d->mat_id[t] >= d->n_mats) return fail(PT_ERR_INVALID, "material id out of range");
+        if (d->light_id[t] >= int32_t(d->n_lights)) return fail(PT_ERR_INVALID, "light id out of range");
+        if (d->prim_ids[t] >= d->n_tris) return fail(PT_ERR_INVALID, "prim_ids entry out of range");
+    }
+    for (uint32_t i = 0; i < d->n_mats; ++i)
+        if (d->mats[i].tex >= int32_t(d->n_textures)) return fail(PT_ERR_INVALID, "texture id out of range");
+    for (uint32_t i = 0; i < d->n_lights; ++i)
+        if (d->lights[i].tri >= d->n_tris) return fail(PT_ERR_INVALID, "light triangle out of range");
+    // walk the tree: every node reachable once, ranges in bounds, depth within the traversal stack
+    std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 1u}};
+    std::vector<uint8_t> seen(d->n_nodes, 0);
+    uint32_t depth = 0;
+    size_t leaf_prims = 0;
+    while (!stack.empty()) {
+        auto [ni, dep] = stack.back();
+        stack.pop_back();
+        if (ni >= d->n_nodes || seen[ni]) return fail(PT_ERR_INVALID, "BVH child index out of range or node shared");
+        seen[ni] = 1;
+        depth = std::max(depth, dep);
+        const pt_bvh_node& n = d->nodes[ni];
+        if (n.count) {
+            if (n.count > 8 || size_t(n.first) + n.count > d->n_tris) return fail(PT_ERR_INVALID, "BVH leaf range out of bounds");
+            leaf_prims += n.count;
+        } else {
+            stack.push_back({n.first, dep + 1});
+            stack.push_back({n.first + 1, dep + 1});
+        }
+    }
+    if (leaf_prims != d->n_tris) return fail(PT_ERR_INVALID, "BVH leaves do not cover every triangle exactly once");
+    if (depth + 2 > uint32_t(kMaxStack)) return fail(PT_ERR_LIMIT, "BVH deeper than the traversal stack (" + std::to_string(kMaxStack - 2) + ")");
+    depth_out = depth;
+    return PT_OK;
+}
+
+int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
+    DevScene& dev = s->dev;
+    // reference-order nodes
+    {
+        std::vector<float4> n(2 * size_t(d->n_nodes));
+        for (uint32_t i = 0; i < d->n_nodes; ++i) {
+            const pt_bvh_node& b = d->nodes[i];
+            uint32_t first = b.first, count = b.count;
+            float ff, fc;
+            std::memcpy(&ff, &first, 4);
+            std::memcpy(&fc, &count, 4);
+            n[2 * size_t(i)] = make_float4(b.lo[0], b.lo[1], b.lo[2], b.hi[0]);
+            n[2 * size_t(i) + 1] = make_float4(b.hi[1], b.hi[2], ff, fc);
+        }
+        if (int rc = upload(s, n.data(), n.size(), &dev.nodes)) return rc;
+    }
+    // triangles in leaf order
+    {
+        std::vector<float4> t(3 * size_t(d->n_tris));
+        for (uint32_t k = 0; k < d->n_tris; ++k) {
+            const uint32_t prim = d->prim_ids[k];
+            const float* p0 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 0] - 1);
+            const float* p1 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 1] - 1);
+            const float* p2 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 2] - 1);
+            float fp;
+            std::memcpy(&fp, &prim, 4);
+            t[3 * size_t(k) + 0] = make_float4(p0[0], p0[1], p0[2], fp);
+            t[3 * size_t(k) + 1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.0f);
+            t[3 * size_t(k) + 2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f);
+        }
+        if (int rc = upload(s, t.data(), t.size(), &dev.tris)) return rc;
+    }
+    // ordered 2-wide nodes: one record per interior node, numbered in binary-node order
+    {
+        std::vector<uint32_t> wide_id(d->n_nodes, 0);
+        uint32_t n_wide = 0;
+        for (uint32_t i = 0; i < d->n_nodes; ++i)
+            if (d->nodes[i].count == 0) wide_id[i] = n_wide++;
+        auto ref_of = [&](uint32_t ni) -> uint32_t {
+            const pt_bvh_node& b = d->nodes[ni];
+            return b.count ? (kLeafBit | (b.count << kLeafCountShift) | b.first) : wide_id[ni];
+        };
+        std::vector<float4> w(4 * size_t(std::max(n_wide, 1u)));
+        for (uint32_t i = 0; i < d->n_nodes; ++i) {
+            const pt_bvh_node& b = d->nodes[i];
+            if (b.count) continue;
+            const pt_bvh_node& c0 = d->nodes[b.first];
+            const pt_bvh_node& c1 = d->nodes[b.first + 1];
+            const uint32_t r0 = ref_of(b.first), r1 = ref_of(b.first + 1);
+            float f0, f1;
+            std::memcpy(&f0, &r0, 4);
+            std::memcpy(&f1, &r1, 4);
+            float4* o = &w[4 * size_t(wide_id[i])];
+            o[0] = make_float4(c0.lo[0], c0.lo[1], c0.lo[2], c0.hi[0]);
+            o[1] = make_float4(c0.hi[1], c0.hi[2], c1.lo[0], c1.lo[1]);
+            o[2] = make_float4(c1.lo[2], c1.hi[0], c1.hi[1], c1.hi[2]);
+            o[3] = make_float4(f0, f1, 0.0f, 0.0f);
+        }
+        dev.wide_root = ref_of(0);
+        if (int rc = upload(s, w.data(), w.size(), &dev.wide)) return rc;
+    }
+    // shading data
+    if (int rc = upload(s, d->verts, 3 * size_t(d->n_verts), &dev.verts)) return rc;
+    if (int rc = upload(s, d->normals, 3 * size_t(d->n_normals), &dev.normals)) return rc;
+    if (int rc = upload(s, d->uvs, 2 * size_t(d->n_uvs), &dev.uvs)) return rc;
+    if (int rc = upload(s, d->vi, 3 * size_t(d->n_tris), &dev.vi)) return rc;
+    if (int rc = upload(s, d->ni, d->ni ? 3 * size_t(d->n_tris) : 0, &dev.ni)) return rc;
+    if (int rc = upload(s, d->ti, d->ti ? 3 * size_t(d->n_tris) : 0, &dev.ti)) return rc;
+    if (int rc = upload(s, d->mat_id, d->n_tris, &dev.mat_id)) return rc;
+    if (int rc = upload(s, d->light_id, d->n_tris, &dev.light_id)) return rc;
+    {
+        std::vector<DevMaterial> m(d->n_mats);
+        for (uint32_t i = 0; i < d->n_mats; ++i) {
+            std::memcpy(m[i].kd, d->mats[i].kd, 12);
+            std::memcpy(m[i].ks, d->mats[i].ks, 12);
+            m[i].ns = d->mats[i].ns;
+            m[i].tex = d->mats[i].tex;
+        }
+        if (int rc = upload(s, m.data(), m.size(), &dev.mats)) return rc;
+        std::vector<DevLight> l(d->n_lights);
+        for (uint32_t i = 0; i < d->n_lights; ++i) {
+            l[i].tri = d->lights[i].tri;
+            std::memcpy(l[i].lemit, d->lights[i].lemit, 12);
+            l[i].inv_area = float(1.0 / double(d->lights[i].area));
+        }
+        if (int rc = upload(s, l.data(), l.size(), &dev.lights)) return rc;
+        std::vector<DevTexture> t(d->n_textures);
+        std::vector<float> texels;
+        for (uint32_t i = 0; i < d->n_textures; ++i) {
+            const pt_texture& src = d->textures[i];
+            if (!src.rgb || src.w == 0 || src.h == 0) return fail(PT_ERR_INVALID, "empty texture");
+            t[i] = DevTexture{src.w, src.h, uint64_t(texels.size())};
+            texels.insert(texels.end(), src.rgb, src.rgb + size_t(3) * src.w * src.h);
+        }
+        if (int rc = upload(s, t.data(), t.size(), &dev.textures)) return rc;
+        if (int rc = upload(s, texels.data(), texels.size(), &dev.tex_data)) return rc;
+    }
+    dev.n_tris = d->n_tris;
+    dev.n_normals = d->ni ? d->n_normals : 0;
+    dev.n_uvs = d->ti ? d->n_uvs : 0;
+    dev.n_lights = d->n_lights;
+    // camera
+    std::memcpy(dev.cam.s2c, d->camera.sample2camera, 64);
+    std::memcpy(dev.cam.c2w, d->camera.camera2world, 64);
+    std::memcpy(dev.cam.eye, d->camera.eye, 12);
+    dev.cam.proj_nume = d->camera.proj_nume;
+    dev.cam.width = d->camera.width;
+    dev.cam.height = d->camera.height;
+    s->width = d->camera.width;
+    s->height = d->camera.height;
+    // Sobol' tables.  scale and m as in SobolSampler (src/sampler.cpp:89-100); for a power of two log2int is exact.
+    {
+        const uint32_t scale = uint32_t(round_up_pow2(int32_t(std::max(d->camera.width, d->camera.height))));
+        uint32_t m = 0;
+        while ((1u << m) < scale) ++m;
+        s->sob_m = m;
+        dev.sob_scale = scale;
+        std::vector<uint32_t> X(size_t(1024) * scale), Y(size_t(1024) * scale);
+        for (int dim = 0; dim < 1024; ++dim) {
+            uint32_t col[64];
+            for (uint32_t c = 0; c < 2 * m; ++c) col[c] = sobol_word(kVdCSobolMatricesInv[m - 1][c], dim);
+            uint32_t* x = &X[size_t(dim) * scale];
+            uint32_t* y = &Y[size_t(dim) * scale];
+            x[0] = y[0] = 0;
+            for (uint32_t p = 1; p < scale; ++p) {
+                const int low = __builtin_ctz(p);
+                y[p] = y[p & (p - 1)] ^ col[low];      // pixel y occupies bits 0..m-1 of the interval number
+                x[p] = x[p & (p - 1)] ^ col[m + low];  // pixel x occupies bits m..2m-1
+            }
+        }
+        if (int rc = upload(s, X.data(), X.size(), &dev.sob_x)) return rc;
+        if (int rc = upload(s, Y.data(), Y.size(), &dev.sob_y)) return rc;
+    }
+    // tabulated Gaussian filter, radius 2, stddev 0.5 (src/block.cpp:14-25, include/pt/filter.h:26-35)
+    {
+        const float radius = 2.0f, stddev = 0.5f;
+        const float alpha = -1.0f / (2.0f * stddev * stddev);
+        for (int i = 0; i < 32; ++i) {
+            const float pos = (radius * i) / 32;
+            dev.filter[i] = std::max(0.0f, std::exp(alpha * pos * pos) - std::exp(alpha * radius * radius));
+        }
+        dev.filter[32] = 0.0f;
+    }
+    return PT_OK;
+}
+
+// ---- work buffers ---------------------------------------------------------------------------------------------------
+
+template <typename T>
+int ws_alloc(Workspace& ws, T** p, size_t count) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, std::max<size_t>(count, 1) * sizeof(T)));
+    ws.owned.push_back(d);
+    *p = static_cast<T*>(d);
+    return PT_OK;
+}
+
+void ws_release(Workspace& ws) {
+    for (void* p : ws.owned) (void)hipFree(p);
+    ws.owned.clear();
+    if (ws.h_counters) (void)hipHostFree(ws.h_counters);
+    ws = Workspace();
+}
+
+int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
+    if (n_slots > ws.cap_slots || n_frames > ws.frame_cap) {
+        ws_release(ws);
+        for (int k = 0; k < 2; ++k) {
+            if (int rc = ws_alloc(ws, &ws.q[k].a, n_slots)) return rc;
+            if (int rc = ws_alloc(ws, &ws.q[k].b, n_slots)) return rc;
+            if (int rc = ws_alloc(ws, &ws.q[k].c, n_slots)) return rc;
+            if (int rc = ws_alloc(ws, &ws.q[k].slot, n_slots)) return rc;
+            if (int rc = ws_alloc(ws, &ws.q[k].hit, n_slots)) return rc;
+        }
+        if (int rc = ws_alloc(ws, &ws.sh.a, n_slots)) return rc;
+        if (int rc = ws_alloc(ws, &ws.sh.b, n_slots)) return rc;
+        if (int rc = ws_alloc(ws, &ws.sh.c, n_slots)) return rc;
+        if (int rc = ws_alloc(ws, &ws.lbuf, n_slots)) return rc;
+        if (int rc = ws_alloc(ws, &ws.counters, 4)) return rc;
+        if (int rc = ws_alloc(ws, &ws.frame_tab, n_frames * 1024)) return rc;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ws.h_counters), 4 * sizeof(uint32_t), hipHostMallocDefault));
+        ws.cap_slots = n_slots;
+        ws.frame_cap = n_frames;
+    }
+    return PT_OK;
+}
+
+// ---- per-kernel timing with HIP events on the launch stream ---------------------------------------------------------
+
+struct Timer {
+    pt_hip_scene* s;
+    bool on;
+    int begin(int kind) {
+        if (!on) return PT_OK;
+        EventPool& p = s->events;
+        if (p.used * 2 + 2 > p.ev.size()) {
+            for (int k = 0; k < 2; ++k) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                p.ev.push_back(e);
+            }
+            p.kind.push_back(kind);
+        }
+        p.kind[p.used] = kind;
+        HIP_TRY(hipEventRecord(p.ev[2 * p.used], g_stream));
+        return PT_OK;
+    }
+    int end() {
+        if (!on) return PT_OK;
+        EventPool& p = s->events;
+        HIP_TRY(hipEventRecord(p.ev[2 * p.used + 1], g_stream));
+        ++p.used;
+        return PT_OK;
+    }
+    // call after a stream synchronisation
+    int collect(pt_stats* st) {
+        EventPool& p = s->events;
+        for (size_t i = 0; i < p.used; ++i) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+            if (st) {
+                st->kernel_ms[p.kind[i]] += ms;
+                st->kernel_launches[p.kind[i]] += 1;
+            }
+        }
+        p.used = 0;
+        return PT_OK;
+    }
+};
+
+inline uint32_t blocks(uint32_t n, uint32_t b) { return (n + b - 1) / b; }
+
+// The bounce loop shared by pt_hip_render_device and pt_hip_li.  Queue 0 of the workspace holds the paths that
+// k_generate left alive; counters were read back into h_counters[0].
+int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm) {
+    Workspace& ws = s->ws;
+    const Counters cnt{ws.counters};
+    uint32_t n_active = ws.h_counters[0];
+    int cur = 0;
+    // every loop iteration is one bounce; specular chains do not advance the bounce counter (src/integrator.cpp:84-87),
+    // so bound the loop independently
+    for (uint32_t iter = 0; n_active > 0 && iter < 8 * pa.max_bounce; ++iter) {
+        HIP_TRY(hipMemsetAsync(ws.counters, 0, 2 * sizeof(uint32_t), g_stream));
+        if (int rc = tm.begin(PT_K_SHADE)) return rc;
+        hipLaunchKernelGGL(k_shade, dim3(blocks(n_active, 256)), dim3(256), 0, g_stream, s->dev, pa, ws.q[cur], n_active, ws.q[cur ^ 1],
+                           ws.sh, ws.lbuf, cnt);
+        if (int rc = tm.end()) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        const uint32_t n_next = ws.h_counters[0], n_shadow = ws.h_counters[1];
+        if (n_shadow) {
+            if (int rc = tm.begin(PT_K_SHADOW)) return rc;
+            hipLaunchKernelGGL(k_shadow, dim3(blocks(n_shadow, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.sh, n_shadow, pa.traversal,
+                               ws.lbuf);
+            if (int rc = tm.end()) return rc;
+        }
+        if (n_next) {
+            if (int rc = tm.begin(PT_K_EXTEND)) return rc;
+            hipLaunchKernelGGL(k_extend, dim3(blocks(n_next, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.q[cur ^ 1], n_next,
+                               pa.traversal, cnt);
+            if (int rc = tm.end()) return rc;
+        }
+        if (st) {
+            st->any_rays += n_shadow;
+            st->closest_rays += n_next;
+        }
+        n_active = n_next;
+        cur ^= 1;
+    }
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int check_ready(const pt_hip_scene* s) {
+    if (g_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
+    if (!s) return fail(PT_ERR_INVALID, "scene handle is null");
+    return PT_OK;
+}
+
+int normalise(const pt_render_params* in, pt_render_params& p) {
+    if (!in) return fail(PT_ERR_INVALID, "render parameters are null");
+    p = *in;
+    if (p.max_bounce == 0) p.max_bounce = 32;
+    if (p.max_bounce > 63) return fail(PT_ERR_INVALID, "max_bounce must be <= 63");
+    if (p.spp_end <= p.spp_begin) return fail(PT_ERR_INVALID, "empty sample range");
+    if (p.integrator < 0 || p.integrator > 2) return fail(PT_ERR_INVALID, "unknown integrator");
+    if (p.traversal < 0 || p.traversal > 1) return fail(PT_ERR_INVALID, "unknown traversal mode");
+    return PT_OK;
+}
+
+}  // namespace
+
+// ======================================================================================================== C ABI
+
+extern "C" {
+
+const char* pt_hip_last_error(void) { return g_error.c_str(); }
+int pt_hip_abi_version(void) { return PT_HIP_ABI_VERSION; }
+
+int pt_hip_init(int device_ordinal) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(PT_ERR_INVALID, "device ordinal " + std::to_string(device_ordinal) + " out of range (" + std::to_string(n) + " devices)");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    if (g_stream && g_device != device_ordinal) {
+        (void)hipStreamDestroy(g_stream);
+        g_stream = nullptr;
+    }
+    if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device_ordinal;
+    return PT_OK;
+}
+
+int pt_hip_shutdown(void) {
+    if (g_stream) {
+        (void)hipStreamSynchronize(g_stream);
+        (void)hipStreamDestroy(g_stream);
+        g_stream = nullptr;
+    }
+    g_device = -1;
+    return PT_OK;
+}
+
+int pt_hip_scene_create(const pt_scene_desc* desc, pt_hip_scene** out) {
+    if (g_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
+    if (!out) return fail(PT_ERR_INVALID, "output handle pointer is null");
+    uint32_t depth = 0;
+    if (int rc = validate(desc, depth)) return rc;
+    pt_hip_scene* s = new pt_hip_scene();
+    s->depth = depth;
+    if (int rc = build_scene(s, desc)) {
+        pt_hip_scene_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return PT_OK;
+}
+
+int pt_hip_scene_destroy(pt_hip_scene* s) {
+    if (!s) return PT_OK;
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    ws_release(s->ws);
+    for (hipEvent_t e : s->events.ev) (void)hipEventDestroy(e);
+    for (void* p : s->owned) (void)hipFree(p);
+    delete s;
+    return PT_OK;
+}
+
+int pt_hip_intersect_device(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_hit* d_hits, int mode, float* kernel_ms) {
+    if (int rc = check_ready(s)) return rc;
+    if (mode < 0 || mode > 1) return fail(PT_ERR_INVALID, "unknown traversal mode");
+    if (n == 0) return PT_OK;
+    if (!d_rays || !d_hits || n > 0xffffffffull) return fail(PT_ERR_INVALID, "bad ray buffer");
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, g_stream));
+    hipLaunchKernelGGL(k_intersect, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
+                       reinterpret_cast<const float4*>(d_rays), uint32_t(n), reinterpret_cast<float4*>(d_hits), mode, (uint32_t*)nullptr);
+    HIP_TRY(hipEventRecord(e1, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (kernel_ms) *kernel_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PT_OK;
+}
+
+int pt_hip_occluded_device(pt_hip_scene* s, const pt_ray* d_rays, size_t n, uint8_t* d_occ, int mode, float* kernel_ms) {
+    if (int rc = check_ready(s)) return rc;
+    if (mode < 0 || mode > 1) return fail(PT_ERR_INVALID, "unknown traversal mode");
+    if (n == 0) return PT_OK;
+    if (!d_rays || !d_occ || n > 0xffffffffull) return fail(PT_ERR_INVALID, "bad ray buffer");
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, g_stream));
+    hipLaunchKernelGGL(k_occluded, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
+                       reinterpret_cast<const float4*>(d_rays), uint32_t(n), d_occ, (int32_t*)nullptr, mode);
+    HIP_TRY(hipEventRecord(e1, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (kernel_ms) *kernel_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return PT_OK;
+}
+
+int pt_hip_intersect(pt_hip_scene* s, const pt_ray* rays, size_t n, pt_hit* hits, int mode) {
+    if (int rc = check_ready(s)) return rc;
+    if (n == 0) return PT_OK;
+    if (!rays || !hits || n > 0xffffffffull) return fail(PT_ERR_INVALID, "bad ray buffer");
+    pt_ray* d_rays = nullptr;
+    pt_hit* d_hits = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rays), n * sizeof(pt_ray)));
+    if (hipMalloc(reinterpret_cast<void**>(&d_hits), n * sizeof(pt_hit)) != hipSuccess) {
+        (void)hipFree(d_rays);
+        return fail(PT_ERR_DEVICE, "hipMalloc failed for the hit buffer");
+    }
+    int rc = PT_OK;
+    if (hipMemcpy(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice) != hipSuccess) rc = fail(PT_ERR_DEVICE, "ray upload failed");
+    if (!rc) rc = pt_hip_intersect_device(s, d_rays, n, d_hits, mode, nullptr);
+    if (!rc && hipMemcpy(hits, d_hits, n * sizeof(pt_hit), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PT_ERR_DEVICE, "hit download failed");
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    return rc;
+}
+
+int pt_hip_occluded(pt_hip_scene* s, const pt_ray* rays, size_t n, uint8_t* occluded, int32_t* first_prim, int mode) {
+    if (int rc = check_ready(s)) return rc;
+    if (mode < 0 || mode > 1) return fail(PT_ERR_INVALID, "unknown traversal mode");
+    if (n == 0) return PT_OK;
+    if (!rays || !occluded || n > 0xffffffffull) return fail(PT_ERR_INVALID, "bad ray buffer");
+    pt_ray* d_rays = nullptr;
+    uint8_t* d_occ = nullptr;
+    int32_t* d_first = nullptr;
+    int rc = PT_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_rays);
+        (void)hipFree(d_occ);
+        (void)hipFree(d_first);
+    };
+    if (hipMalloc(reinterpret_cast<void**>(&d_rays), n * sizeof(pt_ray)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_occ), n) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_first), n * sizeof(int32_t)) != hipSuccess) {
+        cleanup();
+        return fail(PT_ERR_DEVICE, "hipMalloc failed for the occlusion buffers");
+    }
+    if (hipMemcpy(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice) != hipSuccess) rc = fail(PT_ERR_DEVICE, "ray upload failed");
+    if (!rc) {
+        hipLaunchKernelGGL(k_occluded, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
+                           reinterpret_cast<const float4*>(d_rays), uint32_t(n), d_occ, d_first, mode);
+        if (hipStreamSynchronize(g_stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(PT_ERR_DEVICE, "k_occluded failed");
+    }
+    if (!rc && hipMemcpy(occluded, d_occ, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PT_ERR_DEVICE, "download failed");
+    if (!rc && first_prim && hipMemcpy(first_prim, d_first, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(PT_ERR_DEVICE, "download failed");
+    cleanup();
+    return rc;
+}
+
+int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float* d_film, pt_stats* st) {
+    if (int rc = check_ready(s)) return rc;
+    pt_render_params p;
+    if (int rc = normalise(params, p)) return rc;
+    if (!d_film) return fail(PT_ERR_INVALID, "film pointer is null");
+    const auto t0 = std::chrono::steady_clock::now();
+    if (st) std::memset(st, 0, sizeof(*st));
+    const uint32_t W = s->width, H = s->height;
+    const uint32_t tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+    const uint64_t slots_per_sample = uint64_t(tiles_x) * tiles_y * 64;
+    const uint32_t total_spp = p.spp_end - p.spp_begin;
+    uint32_t spp_pass = p.samples_per_pass;
+    if (spp_pass == 0) spp_pass = uint32_t(std::max<uint64_t>(1, (uint64_t(8) << 20) / slots_per_sample));
+    spp_pass = std::min(spp_pass, total_spp);
+    if (slots_per_sample * spp_pass > 0x7fffffffull) return fail(PT_ERR_LIMIT, "samples_per_pass too large for this resolution");
+    if (spp_pass > 0xffffu) return fail(PT_ERR_LIMIT, "samples_per_pass must be < 65536");
+    if (int rc = ws_reserve(s->ws, uint32_t(slots_per_sample * spp_pass), spp_pass)) return rc;
+    Workspace& ws = s->ws;
+    HIP_TRY(hipMemsetAsync(d_film, 0, sizeof(float) * 4 * size_t(W + 4) * size_t(H + 4), g_stream));
+    Timer tm{s, (p.reserved[0] & 1u) == 0};
+    std::vector<uint32_t> frame_words;
+    for (uint32_t f0 = p.spp_begin; f0 < p.spp_end; f0 += spp_pass) {
+        const uint32_t nf = std::min(spp_pass, p.spp_end - f0);
+        frame_words.resize(size_t(nf) * 1024);
+        for (uint32_t k = 0; k < nf; ++k) {
+            const uint64_t idx = frame_index(s->sob_m, uint64_t(f0) + k);
+            for (int dim = 0; dim < 1024; ++dim) frame_words[size_t(k) * 1024 + dim] = sobol_word(idx, dim);
+        }
+        HIP_TRY(hipMemcpyAsync(ws.frame_tab, frame_words.data(), frame_words.size() * 4, hipMemcpyHostToDevice, g_stream));
+        PassArgs pa{};
+        pa.frame_tab = ws.frame_tab;
+        pa.spp_pass = nf;
+        pa.tiles_x = tiles_x;
+        pa.tiles_y = tiles_y;
+        pa.n_slots = uint32_t(slots_per_sample * nf);
+        pa.integrator = p.integrator;
+        pa.traversal = p.traversal;
+        pa.max_bounce = p.max_bounce;
+        HIP_TRY(hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint32_t), g_stream));
+        if (int rc = tm.begin(PT_K_GENERATE)) return rc;
+        hipLaunchKernelGGL(k_generate, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.lbuf,
+                           Counters{ws.counters});
+        if (int rc = tm.end()) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        if (st) {
+            st->paths += uint64_t(W) * H * nf;
+            st->closest_rays += uint64_t(W) * H * nf;
+        }
+        if (int rc = run_bounces(s, pa, st, tm)) return rc;
+        if (int rc = tm.begin(PT_K_FILM)) return rc;
+        hipLaunchKernelGGL(k_film, dim3(((tiles_x + 1) / 2) * ((tiles_y + 1) / 2)), dim3(256), 0, g_stream, s->dev, pa, ws.lbuf, d_film);
+        if (int rc = tm.end()) return rc;
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipGetLastError());
+        if (st) st->exact_retraces += ws.h_counters[2];
+        if (int rc = tm.collect(st)) return rc;
+    }
+    if (st) st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PT_OK;
+}
+
+int pt_hip_render(pt_hip_scene* s, const pt_render_params* params, float* film, pt_stats* st) {
+    if (int rc = check_ready(s)) return rc;
+    if (!film) return fail(PT_ERR_INVALID, "film pointer is null");
+    const size_t bytes = sizeof(float) * 4 * size_t(s->width + 4) * size_t(s->height + 4);
+    float* d_film = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_film), bytes));
+    int rc = pt_hip_render_device(s, params, d_film, st);
+    if (!rc && hipMemcpy(film, d_film, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PT_ERR_DEVICE, "film download failed");
+    (void)hipFree(d_film);
+    return rc;
+}
+
+int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pixel_xy, const uint32_t* sample_index, size_t n, float* rgb,
+              float* pixel_sample, pt_stats* st) {
+    if (int rc = check_ready(s)) return rc;
+    pt_render_params p;
+    pt_render_params tmp = params ? *params : pt_render_params{};
+    tmp.spp_begin = 0;
+    tmp.spp_end = 1;
+    if (int rc = normalise(&tmp, p)) return rc;
+    if (n == 0) return PT_OK;
+    if (!pixel_xy || !sample_index || !rgb || n > 0x7fffffffull) return fail(PT_ERR_INVALID, "bad sample list");
+    if (st) std::memset(st, 0, sizeof(*st));
+    const auto t0 = std::chrono::steady_clock::now();
+    std::map<uint32_t, uint32_t> local;
+    std::vector<uint32_t> frame_local(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (pixel_xy[2 * i] < 0 || pixel_xy[2 * i + 1] < 0 || uint32_t(pixel_xy[2 * i]) >= s->width || uint32_t(pixel_xy[2 * i + 1]) >= s->height)
+            return fail(PT_ERR_INVALID, "pixel outside the image");
+        auto it = local.emplace(sample_index[i], uint32_t(local.size())).first;
+        frame_local[i] = it->second;
+    }
+    if (local.size() > 0xffffu) return fail(PT_ERR_LIMIT, "more than 65535 distinct sample indices in one call");
+    std::vector<uint32_t> frame_words(local.size() * 1024);
+    for (const auto& kv : local) {
+        const uint64_t idx = frame_index(s->sob_m, kv.first);
+        for (int dim = 0; dim < 1024; ++dim) frame_words[size_t(kv.second) * 1024 + dim] = sobol_word(idx, dim);
+    }
+    if (int rc = ws_reserve(s->ws, uint32_t(n), local.size())) return rc;
+    Workspace& ws = s->ws;
+    int32_t* d_xy = nullptr;
+    uint32_t* d_fl = nullptr;
+    float* d_ps = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_xy);
+        (void)hipFree(d_fl);
+        (void)hipFree(d_ps);
+    };
+    if (hipMalloc(reinterpret_cast<void**>(&d_xy), n * 8) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_fl), n * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_ps), n * 8) != hipSuccess) {
+        cleanup();
+        return fail(PT_ERR_DEVICE, "hipMalloc failed for the sample list");
+    }
+    int rc = PT_OK;
+    auto run = [&]() -> int {
+        HIP_TRY(hipMemcpy(d_xy, pixel_xy, n * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_fl, frame_local.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ws.frame_tab, frame_words.data(), frame_words.size() * 4, hipMemcpyHostToDevice));
+        PassArgs pa{};
+        pa.frame_tab = ws.frame_tab;
+        pa.spp_pass = 1;
+        pa.n_slots = uint32_t(n);
+        pa.integrator = p.integrator;
+        pa.traversal = p.traversal;
+        pa.max_bounce = p.max_bounce;
+        pa.list_xy = d_xy;
+        pa.list_frame = d_fl;
+        pa.list_pixel_sample = d_ps;
+        Timer tm{s, true};
+        HIP_TRY(hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint32_t), g_stream));
+        if (int r = tm.begin(PT_K_GENERATE)) return r;
+        hipLaunchKernelGGL(k_generate, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.lbuf,
+                           Counters{ws.counters});
+        if (int r = tm.end()) return r;
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        if (st) {
+            st->paths += n;
+            st->closest_rays += n;
+        }
+        if (int r = run_bounces(s, pa, st, tm)) return r;
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipGetLastError());
+        if (int r = tm.collect(st)) return r;
+        std::vector<float4> L(n);
+        HIP_TRY(hipMemcpy(L.data(), ws.lbuf, n * sizeof(float4), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            rgb[3 * i] = L[i].x;
+            rgb[3 * i + 1] = L[i].y;
+            rgb[3 * i + 2] = L[i].z;
+        }
+        if (pixel_sample) HIP_TRY(hipMemcpy(pixel_sample, d_ps, n * 8, hipMemcpyDeviceToHost));
+        return PT_OK;
+    };
+    rc = run();
+    cleanup();
+    if (st) st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int pt_hip_sobol(pt_hip_scene* s, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim, size_t n, float* out) {
+    if (int rc = check_ready(s)) return rc;
+    if (n == 0) return PT_OK;
+    if (!pixel_xy || !sample_index || !dim || !out || n > 0x7fffffffull) return fail(PT_ERR_INVALID, "bad argument");
+    std::map<uint32_t, uint32_t> local;
+    std::vector<uint32_t> frame_local(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (pixel_xy[2 * i] < 0 || pixel_xy[2 * i + 1] < 0 || uint32_t(pixel_xy[2 * i]) >= s->dev.sob_scale ||
+            uint32_t(pixel_xy[2 * i + 1]) >= s->dev.sob_scale || dim[i] >= 1024)
+            return fail(PT_ERR_INVALID, "pixel or dimension out of range");
+        frame_local[i] = local.emplace(sample_index[i], uint32_t(local.size())).first->second;
+    }
+    std::vector<uint32_t> frame_words(local.size() * 1024);
+    for (const auto& kv : local) {
+        const uint64_t idx = frame_index(s->sob_m, kv.first);
+        for (int d = 0; d < 1024; ++d) frame_words[size_t(kv.second) * 1024 + d] = sobol_word(idx, d);
+    }
+    void *d_tab = nullptr, *d_xy = nullptr, *d_fl = nullptr, *d_dim = nullptr, *d_out = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {d_tab, d_xy, d_fl, d_dim, d_out}) (void)hipFree(p);
+    };
+    auto run = [&]() -> int {
+        HIP_TRY(hipMalloc(&d_tab, frame_words.size() * 4));
+        HIP_TRY(hipMalloc(&d_xy, n * 8));
+        HIP_TRY(hipMalloc(&d_fl, n * 4));
+        HIP_TRY(hipMalloc(&d_dim, n * 4));
+        HIP_TRY(hipMalloc(&d_out, n * 4));
+        HIP_TRY(hipMemcpy(d_tab, frame_words.data(), frame_words.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_xy, pixel_xy, n * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_fl, frame_local.data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_dim, dim, n * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_sobol, dim3(blocks(uint32_t(n), 256)), dim3(256), 0, g_stream, s->dev, static_cast<const uint32_t*>(d_tab),
+                           static_cast<const int32_t*>(d_xy), static_cast<const uint32_t*>(d_fl), static_cast<const uint32_t*>(d_dim),
+                           uint32_t(n), static_cast<float*>(d_out));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
+        return PT_OK;
+    };
+    const int rc = run();
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"

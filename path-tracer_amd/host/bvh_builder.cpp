@@ -1,0 +1,207 @@
+// Sweep-SAH BVH builder: the host-side topology source for the GPU traversal kernels.
+//
+// Restates BVHTreeBuilder of the reference (src/bvh.cpp:99-234, include/pt/bvh.h:63-116) with 32-bit indices.  The
+// topology (node numbering, leaf contents, child order) must be identical to the reference's because the reference
+// traversal visits children in a fixed order and lets the last equally-near triangle win (src/bvh.cpp:39-53,
+// src/shape.cpp:88).  Sorting uses std::sort / std::stable_partition like the reference so that ties between equal
+// centroid coordinates resolve the way the same standard library resolves them there.
+#include "pt_host_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+namespace pt_host {
+
+namespace {
+
+struct Bounds {
+    float lo[3], hi[3];
+    Bounds() {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::numeric_limits<float>::infinity();  // include/pt/aabb.h:10-13
+            hi[k] = std::numeric_limits<float>::lowest();
+        }
+    }
+    void grow(const float* p) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], p[k]);
+            hi[k] = std::max(hi[k], p[k]);
+        }
+    }
+    void grow(const Bounds& b) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], b.lo[k]);
+            hi[k] = std::max(hi[k], b.hi[k]);
+        }
+    }
+    // include/pt/aabb.h:83-88
+    float halfArea() const {
+        if (hi[0] < lo[0]) return 0.0f;
+        const float w = hi[0] - lo[0], h = hi[1] - lo[1], d = hi[2] - lo[2];
+        return (w + h) * d + w * h;
+    }
+};
+
+class SweepBuilder {
+public:
+    SweepBuilder(const float* verts, const uint32_t* vi, uint32_t n) : n_(n), prim_(n), mark_(n), suffix_(n) {
+        std::vector<float> centroid[3];
+        for (auto& c : centroid) c.resize(n);
+        for (uint32_t t = 0; t < n; ++t) {
+            const float* a = verts + 3 * size_t(vi[3 * t + 0] - 1);
+            const float* b = verts + 3 * size_t(vi[3 * t + 1] - 1);
+            const float* c = verts + 3 * size_t(vi[3 * t + 2] - 1);
+            Bounds bb;  // AABB(v0, v1, v2), include/pt/aabb.h:27-30
+            for (int k = 0; k < 3; ++k) bb.lo[k] = bb.hi[k] = a[k];
+            bb.grow(b);
+            bb.grow(c);
+            prim_[t] = bb;
+            for (int k = 0; k < 3; ++k) centroid[k][t] = ((a[k] + b[k]) + c[k]) / 3.0f;  // src/shape.cpp:44-48
+        }
+        for (int axis = 0; axis < 3; ++axis) {
+            order_[axis].resize(n);
+            std::iota(order_[axis].begin(), order_[axis].end(), uint32_t(0));
+            const std::vector<float>& key = centroid[axis];
+            std::sort(order_[axis].begin(), order_[axis].end(), [&key](uint32_t i, uint32_t j) { return key[i] < key[j]; });
+        }
+    }
+
+    void build(std::vector<pt_bvh_node>& nodes, std::vector<uint32_t>& prim_ids, uint32_t& max_depth) {
+        struct Work {
+            uint32_t node, begin, end, depth;
+        };
+        nodes.clear();
+        nodes.reserve(2 * size_t(n_));
+        nodes.push_back(pt_bvh_node{});
+        store(nodes[0], unite(0, n_));
+        std::vector<Work> todo{Work{0, 0, n_, 1}};
+        max_depth = 0;
+        while (!todo.empty()) {
+            const Work w = todo.back();
+            todo.pop_back();
+            max_depth = std::max(max_depth, w.depth);
+            uint32_t cut = 0;
+            if (w.end - w.begin > 1 && split(load(nodes[w.node]), w.begin, w.end, cut)) {
+                const uint32_t child = uint32_t(nodes.size());
+                nodes[w.node].first = child;
+                nodes[w.node].count = 0;
+                nodes.resize(size_t(child) + 2);
+                Bounds left = unite(w.begin, cut), right = unite(cut, w.end);
+                Work a{child, w.begin, cut, w.depth + 1}, b{child + 1, cut, w.end, w.depth + 1};
+                if (left.halfArea() < right.halfArea()) {  // larger area first: src/bvh.cpp:137-144
+                    std::swap(left, right);
+                    std::swap(a.begin, b.begin);
+                    std::swap(a.end, b.end);
+                }
+                store(nodes[child], left);
+                store(nodes[child + 1], right);
+                if (a.end - a.begin < b.end - b.begin) std::swap(a, b);  // bigger range is processed last: src/bvh.cpp:151-156
+                todo.push_back(a);
+                todo.push_back(b);
+            } else {
+                nodes[w.node].first = w.begin;
+                nodes[w.node].count = w.end - w.begin;
+            }
+        }
+        prim_ids = order_[0];
+        nodes.shrink_to_fit();
+    }
+
+private:
+    static void store(pt_bvh_node& n, const Bounds& b) {
+        for (int k = 0; k < 3; ++k) {
+            n.lo[k] = b.lo[k];
+            n.hi[k] = b.hi[k];
+        }
+    }
+    static Bounds load(const pt_bvh_node& n) {
+        Bounds b;
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = n.lo[k];
+            b.hi[k] = n.hi[k];
+        }
+        return b;
+    }
+    Bounds unite(uint32_t begin, uint32_t end) const {  // include/pt/bvh.h:87-92 (always in axis-0 order)
+        Bounds b;
+        for (uint32_t i = begin; i < end; ++i) b.grow(prim_[order_[0][i]]);
+        return b;
+    }
+    // include/pt/bvh.h:98-100: area * (count - 1.0f)
+    static float partCost(uint32_t begin, uint32_t end, const Bounds& b) { return b.halfArea() * (float(end - begin) - 1.0f); }
+
+    // src/bvh.cpp:201-234
+    void sweep(int axis, uint32_t begin, uint32_t end, uint32_t& best_pos, float& best_cost, int& best_axis) {
+        const std::vector<uint32_t>& ord = order_[axis];
+        uint32_t stop = begin;
+        Bounds acc;
+        uint32_t i = end - 1;
+        while (i > begin) {  // right-to-left in chunks of 32 with an early exit between chunks
+            const uint32_t chunk_end = i - std::min(i - begin, uint32_t(32));
+            float c = 0.0f;
+            while (i > chunk_end) {
+                acc.grow(prim_[ord[i]]);
+                c = partCost(i, end, acc);
+                suffix_[i] = c;
+                --i;
+            }
+            if (c > best_cost) {
+                stop = i;
+                break;
+            }
+        }
+        Bounds pre;
+        for (uint32_t k = begin; k < stop; ++k) pre.grow(prim_[ord[k]]);
+        for (uint32_t k = stop; k + 1 < end; ++k) {
+            pre.grow(prim_[ord[k]]);
+            const float lc = partCost(begin, k + 1, pre);
+            const float total = lc + suffix_[k + 1];
+            if (total < best_cost) {
+                best_pos = k + 1;
+                best_cost = total;
+                best_axis = axis;
+            } else if (lc > best_cost) {
+                break;
+            }
+        }
+    }
+
+    // src/bvh.cpp:168-199
+    bool split(const Bounds& bounds, uint32_t begin, uint32_t end, uint32_t& cut) {
+        const float whole = bounds.halfArea() * float(end - begin);  // include/pt/bvh.h:94-96
+        uint32_t pos = (begin + end + 1) / 2;
+        float cost = whole;
+        int axis = 0;
+        for (int a = 0; a < 3; ++a) sweep(a, begin, end, pos, cost, axis);
+        if (cost >= whole) {
+            if (end - begin <= 8) return false;  // MaxLeafSize
+            pos = (begin + end + 1) / 2;
+            axis = 0;  // AABB::getMaxAxis() yields 0 whatever the extents are (include/pt/aabb.h:123-128)
+        }
+        for (uint32_t i = begin; i < pos; ++i) mark_[order_[axis][i]] = 1;
+        for (uint32_t i = pos; i < end; ++i) mark_[order_[axis][i]] = 0;
+        for (int a = 0; a < 3; ++a)
+            if (a != axis)
+                std::stable_partition(order_[a].begin() + begin, order_[a].begin() + end, [this](uint32_t p) { return mark_[p] != 0; });
+        cut = pos;
+        return true;
+    }
+
+    uint32_t n_;
+    std::vector<Bounds> prim_;
+    std::vector<uint8_t> mark_;
+    std::vector<float> suffix_;
+    std::vector<uint32_t> order_[3];
+};
+
+}  // namespace
+
+void build_bvh(const float* verts, const uint32_t* vi, uint32_t n_tris, std::vector<pt_bvh_node>& nodes,
+               std::vector<uint32_t>& prim_ids, uint32_t& max_depth) {
+    SweepBuilder b(verts, vi, n_tris);
+    b.build(nodes, prim_ids, max_depth);
+}
+
+}  // namespace pt_host
