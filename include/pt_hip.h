@@ -127,9 +127,13 @@ typedef struct pt_render_params {
     uint32_t max_bounce;       /* 32 in the reference (src/integrator.cpp:50); 0 selects 32 */
     int32_t  integrator;       /* PT_INTEGRATOR_* */
     int32_t  traversal;        /* PT_TRAVERSE_* */
-    uint32_t samples_per_pass; /* samples of every pixel in flight at once; 0 = choose from free memory */
-    uint32_t reserved[2];
+    uint32_t samples_per_pass; /* samples of every pixel in flight at once; 0 = about 8M paths in flight */
+    uint32_t flags;            /* PT_FLAG_* */
+    uint32_t reserved;
 } pt_render_params;
+
+#define PT_FLAG_NO_KERNEL_TIMING 1u /* do not bracket kernels with HIP events (pt_stats.kernel_ms stays 0) */
+#define PT_FLAG_COUNT_WORK 2u       /* run the instrumented kernels: pt_stats.nodes_fetched / tris_fetched are filled */
 
 #define PT_MAX_KERNEL_STATS 8
 typedef struct pt_stats {
@@ -137,6 +141,8 @@ typedef struct pt_stats {
     uint64_t closest_rays;    /* closest-hit queries (Scene::rayIntersect(ray, its)) */
     uint64_t any_rays;        /* any-hit queries (Scene::unocculded) */
     uint64_t exact_retraces;  /* FAST-mode rays re-traced in EXACT mode */
+    uint64_t nodes_fetched;   /* BVH node records read by all traversals (PT_FLAG_COUNT_WORK only) */
+    uint64_t tris_fetched;    /* triangle records read by all traversals (PT_FLAG_COUNT_WORK only) */
     double   seconds;         /* wall time of the call, device work included */
     /* per-kernel device time (HIP events on the launch stream) and launch counts */
     double   kernel_ms[PT_MAX_KERNEL_STATS];

@@ -41,10 +41,12 @@ struct PassArgs {
     float* list_pixel_sample;
 };
 
-// counters[0] = entries in the next path queue, [1] = entries in the shadow queue, [2] = exact re-traces
+// counters[0] = entries in the next path queue, [1] = entries in the shadow queue, [2] = exact re-traces,
+// [4..5] = node records fetched (u64), [6..7] = triangle records fetched (u64); the last two only in counting builds
 struct Counters {
     uint32_t* v;
 };
+constexpr int kCounterWords = 8;
 
 PTD uint32_t lane_id() { return __lane_id(); }
 
@@ -61,54 +63,80 @@ PTD uint32_t wave_alloc(bool want, uint32_t* counter) {
     return base + uint32_t(__popcll(mask & ((1ull << lane_id()) - 1ull)));
 }
 
-PTD bool trace_closest(const DevScene& sc, int traversal, const RayD& ray, HitD& hit, uint32_t* lds, uint32_t* retrace_counter) {
-    if (traversal == 0) return closest_exact(sc, ray, hit, lds);
+template <class C>
+PTD bool trace_closest(const DevScene& sc, int traversal, const RayD& ray, HitD& hit, uint32_t* lds, uint32_t* retrace_counter, C& wc) {
+    if (traversal == 0) return closest_exact(sc, ray, hit, lds, wc);
     bool tie;
-    bool found = closest_fast(sc, ray, hit, tie, lds);
+    bool found = closest_fast(sc, ray, hit, tie, lds, wc);
     if (tie) {  // two triangles at the same distance: let the reference's visit order decide
-        found = closest_exact(sc, ray, hit, lds);
+        found = closest_exact(sc, ray, hit, lds, wc);
         if (retrace_counter) atomicAdd(retrace_counter, 1u);
     }
     return found;
 }
 
-PTD bool trace_any(const DevScene& sc, int traversal, const RayD& ray, uint32_t* lds) {
+template <class C>
+PTD bool trace_any(const DevScene& sc, int traversal, const RayD& ray, uint32_t* lds, C& wc) {
     if (traversal == 0) {
         int32_t fp;
-        return any_exact(sc, ray, fp, lds);
+        return any_exact(sc, ray, fp, lds, wc);
     }
-    return any_fast(sc, ray, lds);
+    return any_fast(sc, ray, lds, wc);
+}
+
+// add a wave's work counters to the global 64-bit totals (counting builds only)
+PTD void flush_counts(const NoCount&, uint32_t*) {}
+PTD void flush_counts(const Count& c, uint32_t* words) {
+    if (!words) return;
+    uint32_t n = c.nodes, t = c.tris;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n += uint32_t(__shfl_xor(int(n), off));
+        t += uint32_t(__shfl_xor(int(t), off));
+    }
+    if (lane_id() == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(words + 4), (unsigned long long)n);
+        atomicAdd(reinterpret_cast<unsigned long long*>(words + 6), (unsigned long long)t);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ batched queries
 
+template <class C>
 __global__ __launch_bounds__(kBlock) void k_intersect(DevScene sc, const float4* rays, uint32_t n, float4* hits, int mode,
-                                                       uint32_t* retrace_counter) {
+                                                       uint32_t* counters) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
-    const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
-    HitD h;
-    trace_closest(sc, mode, ray, h, s_stack + threadIdx.x, retrace_counter);
-    hits[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+    C wc;
+    if (i < n) {
+        const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
+        const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
+        HitD h;
+        trace_closest(sc, mode, ray, h, s_stack + threadIdx.x, counters ? counters + 2 : nullptr, wc);
+        hits[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+    }
+    flush_counts(wc, counters);
 }
 
+template <class C>
 __global__ __launch_bounds__(kBlock) void k_occluded(DevScene sc, const float4* rays, uint32_t n, uint8_t* occ, int32_t* first_prim,
-                                                      int mode) {
+                                                      int mode, uint32_t* counters) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
-    const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
-    bool hit;
-    int32_t fp = -2;
-    if (mode == 0)
-        hit = any_exact(sc, ray, fp, s_stack + threadIdx.x);
-    else
-        hit = any_fast(sc, ray, s_stack + threadIdx.x);
-    occ[i] = hit ? 1 : 0;
-    if (first_prim) first_prim[i] = hit ? fp : -1;
+    C wc;
+    if (i < n) {
+        const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
+        const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
+        bool hit;
+        int32_t fp = -2;
+        if (mode == 0)
+            hit = any_exact(sc, ray, fp, s_stack + threadIdx.x, wc);
+        else
+            hit = any_fast(sc, ray, s_stack + threadIdx.x, wc);
+        occ[i] = hit ? 1 : 0;
+        if (first_prim) first_prim[i] = hit ? fp : -1;
+    }
+    flush_counts(wc, counters);
 }
 
 // ------------------------------------------------------------------------------------------------ generate + first extend
@@ -116,8 +144,10 @@ __global__ __launch_bounds__(kBlock) void k_occluded(DevScene sc, const float4* 
 // renderBlock's per-sample prologue (src/main.cpp:63-68): startPixelSample, pixelSample = pixel + samplePixel2D(),
 // then the camera ray and the first Scene::rayIntersect of PathIntegrator::Li (src/integrator.cpp:46-53).
 // For the two AOV integrators (src/integrator.cpp:20-43) the result is final and goes straight to lbuf.
+template <class C>
 __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, PathQ q, float4* lbuf, Counters cnt) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    C wc;
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     bool valid = slot < pa.n_slots;
     uint32_t px = 0, py = 0, frame = 0;
@@ -148,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
             pa.list_pixel_sample[2 * size_t(slot) + 1] = ps.y;
         }
         camera_ray(sc.cam, ps, ray.o, ray.d, ray.tmin, ray.tmax);
-        alive = trace_closest(sc, pa.traversal, ray, h, s_stack + threadIdx.x, cnt.v + 2);
+        alive = trace_closest(sc, pa.traversal, ray, h, s_stack + threadIdx.x, cnt.v + 2, wc);
         V3 out = mk3(0.0f);
         if (alive && pa.integrator != 0) {
             Surf it;
@@ -160,6 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
     } else if (slot < pa.n_slots) {
         lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+    flush_counts(wc, cnt.v);
     const uint32_t dst = wave_alloc(alive, cnt.v + 0);
     if (alive) {
         q.a[dst] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
@@ -173,15 +204,19 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
 // ------------------------------------------------------------------------------------------------ extend (bounce >= 1)
 
 // Scene::rayIntersect for rays spawned by Intersection::genRay (src/shape.cpp:186-189): tmin 0, tmax +inf.
+template <class C>
 __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathQ q, uint32_t n, int traversal, Counters cnt) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4 a = q.a[i], b = q.b[i];
-    const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
-    HitD h;
-    trace_closest(sc, traversal, ray, h, s_stack + threadIdx.x, cnt.v + 2);
-    q.hit[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+    C wc;
+    if (i < n) {
+        const float4 a = q.a[i], b = q.b[i];
+        const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
+        HitD h;
+        trace_closest(sc, traversal, ray, h, s_stack + threadIdx.x, cnt.v + 2, wc);
+        q.hit[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+    }
+    flush_counts(wc, cnt.v);
 }
 
 // ------------------------------------------------------------------------------------------------ shade
@@ -318,21 +353,25 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, PathQ i
 // ------------------------------------------------------------------------------------------------ shadow
 
 // Visibility test of sampleLd (src/integrator.cpp:124-126): unoccluded rays add their contribution.
-__global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, ShadowQ sh, uint32_t n, int traversal, float4* lbuf) {
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, ShadowQ sh, uint32_t n, int traversal, float4* lbuf, Counters cnt) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4 a = sh.a[i], b = sh.b[i];
-    const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
-    if (!trace_any(sc, traversal, ray, s_stack + threadIdx.x)) {
-        const float4 c = sh.c[i];
-        const uint32_t slot = as_u(b.w);
-        float4 L = lbuf[slot];
-        L.x += c.x;
-        L.y += c.y;
-        L.z += c.z;
-        lbuf[slot] = L;
+    C wc;
+    if (i < n) {
+        const float4 a = sh.a[i], b = sh.b[i];
+        const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
+        if (!trace_any(sc, traversal, ray, s_stack + threadIdx.x, wc)) {
+            const float4 c = sh.c[i];
+            const uint32_t slot = as_u(b.w);
+            float4 L = lbuf[slot];
+            L.x += c.x;
+            L.y += c.y;
+            L.z += c.z;
+            lbuf[slot] = L;
+        }
     }
+    flush_counts(wc, cnt.v);
 }
 
 // ------------------------------------------------------------------------------------------------ film
@@ -358,8 +397,15 @@ __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const fl
             Sampler smp;
             smp.start(sc, pa.frame_tab + size_t(s) * 1024u, px, py, 2);
             const V2 j = smp.pixel2();
-            // film coordinates (border included), relative to the patch origin
-            const float lx = (float(int(px)) + j.x) + 2.0f, ly = (float(int(py)) + j.y) + 2.0f;
+            // The reference splats into a 32x32 block image first (src/main.cpp:54-74), so positions and filter weights
+            // are evaluated in block-local coordinates: (sample - block offset) + border.
+            const int bx = int(px & ~31u), by = int(py & ~31u);
+            const float qx = (float(int(px)) + j.x) - float(bx), qy = (float(int(py)) + j.y) - float(by);
+            // ImageBlock::put drops a sample whose rounded position leaves its block (src/block.cpp:67-71); that happens
+            // when pixel + jitter rounds up to the next integer in the last column or row of a block
+            const float sx = float(min(32, int(sc.cam.width) - bx)), sy = float(min(32, int(sc.cam.height) - by));
+            if (qx < 0.0f || qx >= sx || qy < 0.0f || qy >= sy) continue;
+            const float lx = qx + 2.0f, ly = qy + 2.0f;
             const int x0 = int(ceilf(lx - 2.0f)), x1 = int(floorf(lx + 2.0f));
             const int y0 = int(ceilf(ly - 2.0f)), y1 = int(floorf(ly + 2.0f));
             float wx[5], wy[5];
@@ -368,7 +414,8 @@ __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const fl
                 wx[k] = sc.filter[min(int(fabsf(float(x0 + k) - lx) * 16.0f), 32)];
                 wy[k] = sc.filter[min(int(fabsf(float(y0 + k) - ly) * 16.0f), 32)];
             }
-            const int ox = x0 - int(16u * rx), oy = y0 - int(16u * ry);
+            // block-local film index -> patch index (the patch starts at film coordinate 16 * region)
+            const int ox = bx + x0 - int(16u * rx), oy = by + y0 - int(16u * ry);
 #pragma unroll
             for (int yy = 0; yy < 5; ++yy) {
                 if (y0 + yy > y1) break;

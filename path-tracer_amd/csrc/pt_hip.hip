@@ -73,7 +73,7 @@ struct Workspace {
     PathQ q[2]{};
     ShadowQ sh{};
     float4* lbuf = nullptr;
-    uint32_t* counters = nullptr;  // device, 4 words
+    uint32_t* counters = nullptr;  // device, kCounterWords words
     uint32_t* h_counters = nullptr;  // pinned host mirror
     uint32_t* frame_tab = nullptr;
     size_t frame_cap = 0;  // in frames
@@ -338,9 +338,9 @@ int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
         if (int rc = ws_alloc(ws, &ws.sh.b, n_slots)) return rc;
         if (int rc = ws_alloc(ws, &ws.sh.c, n_slots)) return rc;
         if (int rc = ws_alloc(ws, &ws.lbuf, n_slots)) return rc;
-        if (int rc = ws_alloc(ws, &ws.counters, 4)) return rc;
+        if (int rc = ws_alloc(ws, &ws.counters, kCounterWords)) return rc;
         if (int rc = ws_alloc(ws, &ws.frame_tab, n_frames * 1024)) return rc;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ws.h_counters), 4 * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ws.h_counters), kCounterWords * sizeof(uint32_t), hipHostMallocDefault));
         ws.cap_slots = n_slots;
         ws.frame_cap = n_frames;
     }
@@ -394,7 +394,7 @@ inline uint32_t blocks(uint32_t n, uint32_t b) { return (n + b - 1) / b; }
 
 // The bounce loop shared by pt_hip_render_device and pt_hip_li.  Queue 0 of the workspace holds the paths that
 // k_generate left alive; counters were read back into h_counters[0].
-int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm) {
+int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bool count) {
     Workspace& ws = s->ws;
     const Counters cnt{ws.counters};
     uint32_t n_active = ws.h_counters[0];
@@ -407,19 +407,27 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm) {
         hipLaunchKernelGGL(k_shade, dim3(blocks(n_active, 256)), dim3(256), 0, g_stream, s->dev, pa, ws.q[cur], n_active, ws.q[cur ^ 1],
                            ws.sh, ws.lbuf, cnt);
         if (int rc = tm.end()) return rc;
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
         const uint32_t n_next = ws.h_counters[0], n_shadow = ws.h_counters[1];
         if (n_shadow) {
             if (int rc = tm.begin(PT_K_SHADOW)) return rc;
-            hipLaunchKernelGGL(k_shadow, dim3(blocks(n_shadow, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.sh, n_shadow, pa.traversal,
-                               ws.lbuf);
+            if (count)
+                hipLaunchKernelGGL(k_shadow<Count>, dim3(blocks(n_shadow, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.sh, n_shadow,
+                                   pa.traversal, ws.lbuf, cnt);
+            else
+                hipLaunchKernelGGL(k_shadow<NoCount>, dim3(blocks(n_shadow, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.sh, n_shadow,
+                                   pa.traversal, ws.lbuf, cnt);
             if (int rc = tm.end()) return rc;
         }
         if (n_next) {
             if (int rc = tm.begin(PT_K_EXTEND)) return rc;
-            hipLaunchKernelGGL(k_extend, dim3(blocks(n_next, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.q[cur ^ 1], n_next,
-                               pa.traversal, cnt);
+            if (count)
+                hipLaunchKernelGGL(k_extend<Count>, dim3(blocks(n_next, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.q[cur ^ 1], n_next,
+                                   pa.traversal, cnt);
+            else
+                hipLaunchKernelGGL(k_extend<NoCount>, dim3(blocks(n_next, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.q[cur ^ 1], n_next,
+                                   pa.traversal, cnt);
             if (int rc = tm.end()) return rc;
         }
         if (st) {
@@ -518,7 +526,7 @@ int pt_hip_intersect_device(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, g_stream));
-    hipLaunchKernelGGL(k_intersect, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
+    hipLaunchKernelGGL(k_intersect<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
                        reinterpret_cast<const float4*>(d_rays), uint32_t(n), reinterpret_cast<float4*>(d_hits), mode, (uint32_t*)nullptr);
     HIP_TRY(hipEventRecord(e1, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
@@ -540,8 +548,8 @@ int pt_hip_occluded_device(pt_hip_scene* s, const pt_ray* d_rays, size_t n, uint
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, g_stream));
-    hipLaunchKernelGGL(k_occluded, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
-                       reinterpret_cast<const float4*>(d_rays), uint32_t(n), d_occ, (int32_t*)nullptr, mode);
+    hipLaunchKernelGGL(k_occluded<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
+                       reinterpret_cast<const float4*>(d_rays), uint32_t(n), d_occ, (int32_t*)nullptr, mode, (uint32_t*)nullptr);
     HIP_TRY(hipEventRecord(e1, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     HIP_TRY(hipGetLastError());
@@ -595,8 +603,8 @@ int pt_hip_occluded(pt_hip_scene* s, const pt_ray* rays, size_t n, uint8_t* occl
     }
     if (hipMemcpy(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice) != hipSuccess) rc = fail(PT_ERR_DEVICE, "ray upload failed");
     if (!rc) {
-        hipLaunchKernelGGL(k_occluded, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
-                           reinterpret_cast<const float4*>(d_rays), uint32_t(n), d_occ, d_first, mode);
+        hipLaunchKernelGGL(k_occluded<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
+                           reinterpret_cast<const float4*>(d_rays), uint32_t(n), d_occ, d_first, mode, (uint32_t*)nullptr);
         if (hipStreamSynchronize(g_stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(PT_ERR_DEVICE, "k_occluded failed");
     }
     if (!rc && hipMemcpy(occluded, d_occ, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PT_ERR_DEVICE, "download failed");
@@ -625,7 +633,8 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
     if (int rc = ws_reserve(s->ws, uint32_t(slots_per_sample * spp_pass), spp_pass)) return rc;
     Workspace& ws = s->ws;
     HIP_TRY(hipMemsetAsync(d_film, 0, sizeof(float) * 4 * size_t(W + 4) * size_t(H + 4), g_stream));
-    Timer tm{s, (p.reserved[0] & 1u) == 0};
+    Timer tm{s, (p.flags & PT_FLAG_NO_KERNEL_TIMING) == 0};
+    const bool count = (p.flags & PT_FLAG_COUNT_WORK) != 0;
     std::vector<uint32_t> frame_words;
     for (uint32_t f0 = p.spp_begin; f0 < p.spp_end; f0 += spp_pass) {
         const uint32_t nf = std::min(spp_pass, p.spp_end - f0);
@@ -644,25 +653,33 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         pa.integrator = p.integrator;
         pa.traversal = p.traversal;
         pa.max_bounce = p.max_bounce;
-        HIP_TRY(hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint32_t), g_stream));
+        HIP_TRY(hipMemsetAsync(ws.counters, 0, kCounterWords * sizeof(uint32_t), g_stream));
         if (int rc = tm.begin(PT_K_GENERATE)) return rc;
-        hipLaunchKernelGGL(k_generate, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.lbuf,
-                           Counters{ws.counters});
+        if (count)
+            hipLaunchKernelGGL(k_generate<Count>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.lbuf,
+                               Counters{ws.counters});
+        else
+            hipLaunchKernelGGL(k_generate<NoCount>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0],
+                               ws.lbuf, Counters{ws.counters});
         if (int rc = tm.end()) return rc;
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
         if (st) {
             st->paths += uint64_t(W) * H * nf;
             st->closest_rays += uint64_t(W) * H * nf;
         }
-        if (int rc = run_bounces(s, pa, st, tm)) return rc;
+        if (int rc = run_bounces(s, pa, st, tm, count)) return rc;
         if (int rc = tm.begin(PT_K_FILM)) return rc;
         hipLaunchKernelGGL(k_film, dim3(((tiles_x + 1) / 2) * ((tiles_y + 1) / 2)), dim3(256), 0, g_stream, s->dev, pa, ws.lbuf, d_film);
         if (int rc = tm.end()) return rc;
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
         HIP_TRY(hipGetLastError());
-        if (st) st->exact_retraces += ws.h_counters[2];
+        if (st) {
+            st->exact_retraces += ws.h_counters[2];
+            st->nodes_fetched += uint64_t(ws.h_counters[4]) | (uint64_t(ws.h_counters[5]) << 32);
+            st->tris_fetched += uint64_t(ws.h_counters[6]) | (uint64_t(ws.h_counters[7]) << 32);
+        }
         if (int rc = tm.collect(st)) return rc;
     }
     if (st) st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -738,18 +755,23 @@ int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pi
         pa.list_frame = d_fl;
         pa.list_pixel_sample = d_ps;
         Timer tm{s, true};
-        HIP_TRY(hipMemsetAsync(ws.counters, 0, 4 * sizeof(uint32_t), g_stream));
+        const bool count = (p.flags & PT_FLAG_COUNT_WORK) != 0;
+        HIP_TRY(hipMemsetAsync(ws.counters, 0, kCounterWords * sizeof(uint32_t), g_stream));
         if (int r = tm.begin(PT_K_GENERATE)) return r;
-        hipLaunchKernelGGL(k_generate, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.lbuf,
-                           Counters{ws.counters});
+        if (count)
+            hipLaunchKernelGGL(k_generate<Count>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.lbuf,
+                               Counters{ws.counters});
+        else
+            hipLaunchKernelGGL(k_generate<NoCount>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0],
+                               ws.lbuf, Counters{ws.counters});
         if (int r = tm.end()) return r;
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
         if (st) {
             st->paths += n;
             st->closest_rays += n;
         }
-        if (int r = run_bounces(s, pa, st, tm)) return r;
+        if (int r = run_bounces(s, pa, st, tm, count)) return r;
         HIP_TRY(hipStreamSynchronize(g_stream));
         HIP_TRY(hipGetLastError());
         if (int r = tm.collect(st)) return r;

@@ -48,6 +48,18 @@ struct RayD {
     float tmin, tmax;
 };
 
+// Work counters (node records fetched, triangle records fetched).  NoCount compiles to nothing; Count is used by the
+// instrumented kernel instantiations that produce the per-ray averages for the bandwidth model.
+struct NoCount {
+    PTD void node() {}
+    PTD void tri() {}
+};
+struct Count {
+    uint32_t nodes = 0, tris = 0;
+    PTD void node() { ++nodes; }
+    PTD void tri() { ++tris; }
+};
+
 struct HitD {
     int32_t prim;
     float t, u, v;
@@ -114,7 +126,8 @@ PTD void load_tri(const DevScene& sc, uint32_t slot, V3& p0, V3& e1, V3& e2, int
 // ------------------------------------------------------------------------------------------------ reference order
 
 // Closest hit in the reference's visit order.  Returns true when something was hit.
-PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t* lds_stack) {
+template <class C>
+PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t* lds_stack, C& wc) {
     Stack st;
     st.init(lds_stack);
     st.push(0u);
@@ -125,6 +138,7 @@ PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t*
     hit.u = hit.v = 0.0f;
     while (!st.empty()) {
         const uint32_t ni = st.pop();
+        wc.node();
         const float4 n0 = sc.nodes[2 * size_t(ni)];
         const float4 n1 = sc.nodes[2 * size_t(ni) + 1];
         const uint32_t first = as_u(n1.z), count = as_u(n1.w);
@@ -133,6 +147,7 @@ PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t*
                 V3 p0, e1, e2;
                 int32_t prim;
                 load_tri(sc, first + k, p0, e1, e2, prim);
+                wc.tri();
                 float t, u, v;
                 if (tri_hit(p0, e1, e2, ray, max_dis, t, u, v)) {
                     max_dis = t;
@@ -152,13 +167,15 @@ PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t*
 }
 
 // Any hit in the reference's visit order; first_prim receives the first accepted triangle or -1.
-PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uint32_t* lds_stack) {
+template <class C>
+PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uint32_t* lds_stack, C& wc) {
     Stack st;
     st.init(lds_stack);
     st.push(0u);
     first_prim = -1;
     while (!st.empty()) {
         const uint32_t ni = st.pop();
+        wc.node();
         const float4 n0 = sc.nodes[2 * size_t(ni)];
         const float4 n1 = sc.nodes[2 * size_t(ni) + 1];
         const uint32_t first = as_u(n1.z), count = as_u(n1.w);
@@ -167,6 +184,7 @@ PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uin
                 V3 p0, e1, e2;
                 int32_t prim;
                 load_tri(sc, first + k, p0, e1, e2, prim);
+                wc.tri();
                 float t, u, v;
                 if (tri_hit(p0, e1, e2, ray, ray.tmax, t, u, v)) {
                     first_prim = prim;
@@ -219,14 +237,18 @@ PTD RayFast make_fast(const RayD& ray) {
     RayFast r;
     r.o = ray.o;
     r.d = ray.d;
-    r.rd = V3{1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z};
+    // a zero direction component would give 0 * inf = NaN for an origin on a slab plane; a huge finite reciprocal gives
+    // 0 there (the ray touches the plane) and +-huge elsewhere, which keeps the test conservative
+    auto rcp = [](float d) { return fabsf(d) < 1e-30f ? copysignf(1e30f, d) : 1.0f / d; };
+    r.rd = V3{rcp(ray.d.x), rcp(ray.d.y), rcp(ray.d.z)};
     r.tmin = ray.tmin;
     return r;
 }
 
 // Ordered closest hit.  `tie` is set when two different triangles were accepted at the same distance: the caller then
 // re-traces the ray with closest_exact so that the winner is the one the reference's visit order picks.
-PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& tie, uint32_t* lds_stack) {
+template <class C>
+PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& tie, uint32_t* lds_stack, C& wc) {
     Stack st;
     st.init(lds_stack);
     const RayFast r = make_fast(ray);
@@ -239,6 +261,7 @@ PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& tie,
     for (;;) {
         if (!(cur & kLeafBit)) {
             const float4* w = sc.wide + 4 * size_t(cur);
+            wc.node();
             const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
             bool h0, h1;
             float n0, n1;
@@ -260,6 +283,7 @@ PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& tie,
                 V3 p0, e1, e2;
                 int32_t prim;
                 load_tri(sc, first + k, p0, e1, e2, prim);
+                wc.tri();
                 float t, u, v;
                 if (tri_hit(p0, e1, e2, ray, best, t, u, v)) {
                     if (t == best && hit.prim >= 0) tie = true;
@@ -279,7 +303,8 @@ PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& tie,
 
 // Ordered any hit (no ordering needed for correctness; children are visited first-listed first, which is the
 // larger-area child the builder stores first for shadow rays).
-PTD bool any_fast(const DevScene& sc, const RayD& ray, uint32_t* lds_stack) {
+template <class C>
+PTD bool any_fast(const DevScene& sc, const RayD& ray, uint32_t* lds_stack, C& wc) {
     Stack st;
     st.init(lds_stack);
     const RayFast r = make_fast(ray);
@@ -287,6 +312,7 @@ PTD bool any_fast(const DevScene& sc, const RayD& ray, uint32_t* lds_stack) {
     for (;;) {
         if (!(cur & kLeafBit)) {
             const float4* w = sc.wide + 4 * size_t(cur);
+            wc.node();
             const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
             bool h0, h1;
             float n0, n1;
@@ -307,6 +333,7 @@ PTD bool any_fast(const DevScene& sc, const RayD& ray, uint32_t* lds_stack) {
                 V3 p0, e1, e2;
                 int32_t prim;
                 load_tri(sc, first + k, p0, e1, e2, prim);
+                wc.tri();
                 float t, u, v;
                 if (tri_hit(p0, e1, e2, ray, ray.tmax, t, u, v)) return true;
             }

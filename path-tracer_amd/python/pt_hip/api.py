@@ -11,6 +11,7 @@ _PKG = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 LIB_DIR = os.path.join(_PKG, "lib")
 
 TRAVERSE_EXACT, TRAVERSE_FAST = 0, 1
+FLAG_NO_KERNEL_TIMING, FLAG_COUNT_WORK = 1, 2
 INTEGRATOR_PATH, INTEGRATOR_NORMAL, INTEGRATOR_ALBEDO = 0, 1, 2
 KERNEL_NAMES = ["generate", "extend", "shade", "shadow", "film", "retrace", "k6", "k7"]
 
@@ -50,15 +51,15 @@ class SceneDesc(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [("spp_begin", C.c_uint32), ("spp_end", C.c_uint32), ("max_bounce", C.c_uint32), ("integrator", C.c_int32),
-                ("traversal", C.c_int32), ("samples_per_pass", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("traversal", C.c_int32), ("samples_per_pass", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64), ("exact_retraces", C.c_uint64),
-                ("seconds", C.c_double), ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8)]
+                ("nodes_fetched", C.c_uint64), ("tris_fetched", C.c_uint64), ("seconds", C.c_double), ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k in ("paths", "closest_rays", "any_rays", "exact_retraces", "seconds")}
+        d = {k: getattr(self, k) for k in ("paths", "closest_rays", "any_rays", "exact_retraces", "nodes_fetched", "tris_fetched", "seconds")}
         d["kernel_ms"] = {KERNEL_NAMES[i]: self.kernel_ms[i] for i in range(8) if self.kernel_launches[i]}
         d["kernel_launches"] = {KERNEL_NAMES[i]: self.kernel_launches[i] for i in range(8) if self.kernel_launches[i]}
         return d
@@ -255,10 +256,10 @@ class Scene:
         _chk(hip_lib().pt_hip_occluded(self.h, rays.ctypes.data, len(rays), _p(occ, c_u8p), _p(first, c_i32p), mode))
         return occ, first
 
-    def params(self, spp_begin, spp_end, integrator=INTEGRATOR_PATH, traversal=TRAVERSE_FAST, samples_per_pass=0, max_bounce=32):
+    def params(self, spp_begin, spp_end, integrator=INTEGRATOR_PATH, traversal=TRAVERSE_EXACT, samples_per_pass=0, max_bounce=32, flags=0):
         p = RenderParams()
         p.spp_begin, p.spp_end, p.max_bounce = spp_begin, spp_end, max_bounce
-        p.integrator, p.traversal, p.samples_per_pass = integrator, traversal, samples_per_pass
+        p.integrator, p.traversal, p.samples_per_pass, p.flags = integrator, traversal, samples_per_pass, flags
         return p
 
     def render(self, spp_begin, spp_end, **kw):

@@ -1,0 +1,156 @@
+"""Deterministic stand-in scenes.
+
+Three of the reference's four scene meshes are not in its tree (.MISSING_LARGE_BLOBS), so the configurations that
+name them run on generated geometry with the reference's own camera, light and material parameters
+(scenes/<name>/<name>.xml and .mtl).  Every generator is a pure function of its arguments.
+"""
+import numpy as np
+
+from .scene import SceneData
+
+
+def _scene(name, verts, tris, mat_id, mats, light_infos, cam, normals=None, ni=None):
+    verts = np.asarray(verts, np.float32).reshape(-1, 3)
+    vi = np.asarray(tris, np.uint32).reshape(-1, 3) + 1
+    n = len(vi)
+    return SceneData(
+        name=name, verts=verts, normals=np.zeros((0, 3), np.float32) if normals is None else np.asarray(normals, np.float32),
+        uvs=np.zeros((0, 2), np.float32), vi=vi, ni=np.zeros((n, 3), np.uint32) if ni is None else np.asarray(ni, np.uint32),
+        ti=np.zeros((n, 3), np.uint32), mat_id=np.asarray(mat_id, np.uint32), mat_names=[m[0] for m in mats],
+        mat_kd=np.asarray([m[1] for m in mats], np.float32).reshape(-1, 3),
+        mat_ks=np.asarray([m[2] for m in mats], np.float32).reshape(-1, 3), mat_ns=np.asarray([m[3] for m in mats], np.float32),
+        mat_tex=np.full(len(mats), -1, np.int32), light_infos=light_infos, **cam)
+
+
+class _Mesh:
+    def __init__(self):
+        self.v, self.t, self.m = [], [], []
+
+    def quad(self, a, b, c, d, mat):
+        i = len(self.v)
+        self.v += [a, b, c, d]
+        self.t += [(i, i + 1, i + 2), (i, i + 2, i + 3)]
+        self.m += [mat, mat]
+
+    def box(self, lo, hi, mat):
+        x0, y0, z0 = lo
+        x1, y1, z1 = hi
+        self.quad((x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0), mat)
+        self.quad((x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1), mat)
+        self.quad((x0, y0, z0), (x0, y0, z1), (x0, y1, z1), (x0, y1, z0), mat)
+        self.quad((x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1), mat)
+        self.quad((x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1), mat)
+        self.quad((x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0), mat)
+
+
+def cornell_box(width=768, height=768):
+    """Classic Cornell box geometry (the published measurement data: 555-unit room, two blocks, ceiling light) with the
+    material names and values of scenes/cornell-box/cornell-box.mtl and the camera/light of cornell-box.xml."""
+    mats = [("DiffuseWhite", (0.79, 0.76, 0.73), (0, 0, 0), 1.0), ("LeftWall", (0.9, 0.14, 0.0), (0, 0, 0), 1.0),
+            ("RightWall", (0.2, 0.86, 0.0), (0, 0, 0), 1.0), ("Light", (0, 0, 0), (0, 0, 0), 1.0)]
+    W, L, R, E = 0, 1, 2, 3
+    m = _Mesh()
+    m.quad((552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2), W)                      # floor
+    m.quad((556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0), W)          # ceiling
+    m.quad((549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2), W)        # back wall
+    m.quad((0, 0, 559.2), (0, 0, 0), (0, 548.8, 0), (0, 548.8, 559.2), R)                      # right wall
+    m.quad((552.8, 0, 0), (549.6, 0, 559.2), (556, 548.8, 559.2), (556, 548.8, 0), L)          # left wall
+    m.quad((343, 548.7, 227), (343, 548.7, 332), (213, 548.7, 332), (213, 548.7, 227), E)      # light, just under the ceiling
+    short = [((130, 165, 65), (82, 165, 225), (240, 165, 272), (290, 165, 114)),
+             ((290, 0, 114), (290, 165, 114), (240, 165, 272), (240, 0, 272)),
+             ((130, 0, 65), (130, 165, 65), (290, 165, 114), (290, 0, 114)),
+             ((82, 0, 225), (82, 165, 225), (130, 165, 65), (130, 0, 65)),
+             ((240, 0, 272), (240, 165, 272), (82, 165, 225), (82, 0, 225))]
+    tall = [((423, 330, 247), (265, 330, 296), (314, 330, 456), (472, 330, 406)),
+            ((423, 0, 247), (423, 330, 247), (472, 330, 406), (472, 0, 406)),
+            ((472, 0, 406), (472, 330, 406), (314, 330, 456), (314, 0, 456)),
+            ((314, 0, 456), (314, 330, 456), (265, 330, 296), (265, 0, 296)),
+            ((265, 0, 296), (265, 330, 296), (423, 330, 247), (423, 0, 247))]
+    for q in short + tall:
+        m.quad(*q, W)
+    cam = dict(width=width, height=height, fovy=float(np.float32(39.3077)), eye=(278.0, 273.0, -800.0), lookat=(278.0, 273.0, -799.0),
+               up=(0.0, 1.0, 0.0))
+    return _scene("cornell-box-synth", m.v, m.t, m.m, mats, [("Light", (34.0, 24.0, 8.0))], cam)
+
+
+def random_soup(n_tris, seed=0, width=64, height=48, extent=4.0, size=0.6, n_lights=4, glossy=True):
+    """Random triangle soup in a cube, a few emissive triangles, a camera looking at it.  For unit and parity tests."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-extent, extent, (n_tris, 1, 3))
+    v = (c + rng.uniform(-size, size, (n_tris, 3, 3))).astype(np.float32).reshape(-1, 3)
+    tris = np.arange(3 * n_tris).reshape(-1, 3)
+    mats = [("grey", (0.5, 0.5, 0.5), (0, 0, 0), 1.0), ("glossy", (0.1, 0.2, 0.3), (0.3, 0.2, 0.1), 50.0 if glossy else 1.0),
+            ("emit", (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]
+    mat_id = rng.integers(0, 2, n_tris)
+    mat_id[rng.choice(n_tris, min(n_lights, n_tris), replace=False)] = 2
+    cam = dict(width=width, height=height, fovy=50.0, eye=(0.0, 0.5, -3.0 * extent), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0))
+    return _scene("soup%d" % n_tris, v, tris, mat_id, mats, [("emit", (20.0, 18.0, 15.0))], cam)
+
+
+def grid_plane(n=16, width=64, height=64):
+    """A flat n x n grid of quads (many equal centroid coordinates and flat boxes: exercises sort ties, the median-split
+    fallback and the equal-distance rule) lit by a small quad above it."""
+    m = _Mesh()
+    for j in range(n):
+        for i in range(n):
+            m.quad((i, 0, j), (i, 0, j + 1), (i + 1, 0, j + 1), (i + 1, 0, j), 0)
+    h = n / 2
+    m.quad((h - 1, 4, h - 1), (h + 1, 4, h - 1), (h + 1, 4, h + 1), (h - 1, 4, h + 1), 1)
+    mats = [("floor", (0.6, 0.6, 0.6), (0.2, 0.2, 0.2), 20.0), ("lamp", (0, 0, 0), (0, 0, 0), 1.0)]
+    cam = dict(width=width, height=height, fovy=45.0, eye=(h, 6.0, -n * 0.8), lookat=(h, 0.0, h), up=(0.0, 1.0, 0.0))
+    return _scene("grid%d" % n, m.v, m.t, m.m, mats, [("lamp", (30.0, 30.0, 30.0))], cam)
+
+
+def library_synth(n_books=40000, seed=0x11B4A47, width=1280, height=720):
+    """Stand-in for the missing library mesh: a room with rows of shelves filled with thin, long boxes ("books"): many
+    small axis-aligned boxes at different scales -> deep BVH, incoherent traversal.  Camera and lights follow
+    scenes/library/library.xml; materials take the three untextured parameter sets of library.mtl (Ns 100 / 5 / 360).
+    Triangle count = 12 * (n_books + shelves + 6 room/lamp boxes)."""
+    rng = np.random.default_rng(seed)
+    m = _Mesh()
+    WALL, WOOD, BOOK_A, BOOK_B, LAMP1, LAMP2 = range(6)
+    mats = [("Walls", (0.6, 0.58, 0.55), (0.0, 0.0, 0.0), 5.0), ("Wood", (0.35, 0.2, 0.1), (0.1, 0.1, 0.1), 100.0),
+            ("BookA", (0.5, 0.1, 0.1), (0.05, 0.05, 0.05), 5.0), ("BookB", (0.1, 0.2, 0.4), (0.2, 0.2, 0.2), 360.0),
+            ("Sconce_Glass.001", (0.5, 0.5, 0.5), (0, 0, 0), 1.0), ("Sconce_Glass", (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]
+    # room 4 x 2.6 x 3 m as an inward-facing box made of six thin slabs
+    X0, X1, Y0, Y1, Z0, Z1 = -2.0, 2.0, 0.0, 2.6, -1.5, 1.5
+    t = 0.05
+    m.box((X0, Y0 - t, Z0), (X1, Y0, Z1), WALL)
+    m.box((X0, Y1, Z0), (X1, Y1 + t, Z1), WALL)
+    m.box((X0 - t, Y0, Z0), (X0, Y1, Z1), WALL)
+    m.box((X1, Y0, Z0), (X1 + t, Y1, Z1), WALL)
+    m.box((X0, Y0, Z0 - t), (X1, Y1, Z0), WALL)
+    m.box((X0, Y0, Z1), (X1, Y1, Z1 + t), WALL)
+    # two sconces (emitters)
+    m.box((-1.9, 1.9, 0.6), (-1.8, 2.1, 0.8), LAMP1)
+    m.box((-1.9, 1.9, -0.2), (-1.8, 2.1, 0.0), LAMP2)
+    # shelving along the -x wall and the +-z walls: boards, then books on the boards
+    boards = []
+    n_levels = 7
+    for lv in range(n_levels):
+        y = 0.1 + lv * 0.33
+        boards.append(((X0 + 0.02, y, Z0 + 0.02), (X0 + 0.32, y + 0.02, Z1 - 0.02), 2))      # run along z
+        boards.append(((X0 + 0.4, y, Z0 + 0.02), (X1 - 0.6, y + 0.02, Z0 + 0.32), 0))        # run along x
+        boards.append(((X0 + 0.4, y, Z1 - 0.32), (X1 - 0.6, y + 0.02, Z1 - 0.02), 0))
+    for lo, hi, _axis in boards:
+        m.box(lo, hi, WOOD)
+    per_board = max(1, n_books // len(boards))
+    for lo, hi, axis in boards:
+        length = hi[axis] - lo[axis]
+        cuts = np.sort(rng.uniform(0, length, per_board + 1))
+        for k in range(per_board):
+            a, b = cuts[k], cuts[k + 1]
+            if b - a < 1e-4:
+                continue
+            hgt = rng.uniform(0.16, 0.29)
+            dep = rng.uniform(0.15, 0.27)
+            blo, bhi = list(lo), list(hi)
+            blo[1], bhi[1] = hi[1], hi[1] + hgt
+            blo[axis], bhi[axis] = lo[axis] + a, lo[axis] + a + (b - a) * 0.92
+            o = 2 if axis == 0 else 0
+            bhi[o] = blo[o] + dep
+            m.box(tuple(blo), tuple(bhi), BOOK_A if rng.random() < 0.5 else BOOK_B)
+    cam = dict(width=width, height=height, fovy=60.0, eye=(float(np.float32(1.6146)), 1.0, float(np.float32(1.0596))),
+               lookat=(float(np.float32(0.2)), float(np.float32(1.2)), float(np.float32(0.7))), up=(0.0, 1.0, 0.0))
+    lights = [("Sconce_Glass.001", (26.0, 26.0, 26.0)), ("Sconce_Glass", (16.0, 14.0, 8.0))]
+    return _scene("library-synth", m.v, m.t, m.m, mats, lights, cam)

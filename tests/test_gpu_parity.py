@@ -1,0 +1,248 @@
+"""GPU parity: the HIP path, called through the C ABI (libpt_hip.so), against the CPU oracle on the same inputs.
+
+Bars: bit-exact for hit triangle index, t, u, v, occlusion flags, first occluder and Sobol' values; radiance within the
+stated tolerances (device sin/cos/pow differ from glibc's by ulps, so paths can diverge after the first BRDF sample).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+import orc
+from pt_hip import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------ sampler
+
+def test_sobol_bit_exact(veach_gpu, veach_sd):
+    rng = np.random.default_rng(0)
+    n = 30000
+    pix = np.stack([rng.integers(0, veach_sd.width, n), rng.integers(0, veach_sd.height, n)], 1).astype(np.int32)
+    smp = rng.integers(0, 4096, n).astype(np.uint32)
+    smp[:100] = np.arange(100)
+    dim = rng.integers(0, 1024, n).astype(np.uint32)
+    dim[:4] = [0, 1, 2, 1023]
+    got = veach_gpu.sobol(pix, smp, dim)
+    want = np.array([orc.sobol_sample(orc.sobol_index(11, int(s), int(p[0]), int(p[1])), int(d)) for p, s, d in zip(pix, smp, dim)],
+                    np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------ traversal
+
+@pytest.fixture(scope="module")
+def veach_rays(veach_oracle):
+    prim = helpers.primary_rays(veach_oracle, sample=0, step=3)
+    closest, shadow = helpers.recorded_rays(veach_oracle, 4000)
+    return prim, closest, shadow
+
+
+def test_closest_hit_exact_mode_bit_exact(veach_gpu, veach_oracle, veach_rays):
+    for rays in veach_rays[:2]:
+        want = veach_oracle.intersect(rays)
+        got = veach_gpu.intersect(rays, api.TRAVERSE_EXACT)
+        assert helpers.hits_equal(got, want).all()
+        assert (want["prim"] >= 0).mean() > 0.5
+
+
+def test_closest_hit_fast_mode(veach_gpu, veach_oracle, veach_rays):
+    """The ordered traversal reports the same triangle, t, u, v as the reference order.  Known exception (documented in
+    DESIGN.md): rays for which the reference's own slab test rejects a box that contains the nearest hit; they are rarer
+    than 1 in 10^5 here and the ordered traversal then reports the nearer triangle."""
+    n_bad = n_all = 0
+    for rays in veach_rays[:2]:
+        want = veach_oracle.intersect(rays)
+        got = veach_gpu.intersect(rays, api.TRAVERSE_FAST)
+        same = helpers.hits_equal(got, want)
+        n_bad += int((~same).sum())
+        n_all += len(rays)
+        bad = np.nonzero(~same)[0]
+        assert (got["t"][bad] < want["t"][bad]).all() or (want["prim"][bad] < 0).all()
+    assert n_bad <= max(1, n_all // 50000)
+
+
+def test_any_hit_bit_exact(veach_gpu, veach_oracle, veach_rays):
+    shadow = veach_rays[2]
+    occ, first = veach_oracle.occluded(shadow)
+    g_occ, g_first = veach_gpu.occluded(shadow, api.TRAVERSE_EXACT)
+    assert np.array_equal(g_occ, occ) and np.array_equal(g_first, first)
+    assert 0.05 < occ.mean() < 0.95
+    f_occ, _ = veach_gpu.occluded(shadow, api.TRAVERSE_FAST)
+    assert (f_occ != occ).sum() <= max(1, len(occ) // 50000)
+
+
+def test_empty_and_degenerate_batches(veach_gpu, veach_oracle):
+    assert len(veach_gpu.intersect(np.zeros((0, 8), np.float32))) == 0
+    assert len(veach_gpu.occluded(np.zeros((0, 8), np.float32))[0]) == 0
+    # axis-parallel directions (zero components -> +-inf and NaN slabs), zero-length range, reversed range
+    rays = np.array([[28.0, 5.0, 0.0, -1, 0, 0, 0, np.inf], [0.0, 20.0, 0.0, 0, -1, 0, 0, np.inf], [0, 3, -20, 0, 0, 1, 0, np.inf],
+                     [28.0, 5.0, 0.0, -1, 0, 0, 5, 5], [28.0, 5.0, 0.0, -1, 0, 0, 9, 1], [0, 0, 0, 0, 0, 0, 0, 1]], np.float32)
+    want = veach_oracle.intersect(rays)
+    for mode in (api.TRAVERSE_EXACT, api.TRAVERSE_FAST):
+        assert helpers.hits_equal(veach_gpu.intersect(rays, mode), want).all()
+    occ, first = veach_oracle.occluded(rays)
+    g_occ, g_first = veach_gpu.occluded(rays, api.TRAVERSE_EXACT)
+    assert np.array_equal(g_occ, occ) and np.array_equal(g_first, first)
+
+
+def test_equal_distance_hits_follow_reference_order():
+    """Rays aimed exactly at shared edges and vertices of a flat grid hit two or more triangles at the same distance;
+    the reference keeps the last one in its visit order (src/bvh.cpp:39-46, src/shape.cpp:88)."""
+    sd = synth.grid_plane(16)
+    o, g = orc.Scene(sd), api.Scene(sd)
+    xs = np.arange(0, 17, 0.5, dtype=np.float32)
+    gx, gz = np.meshgrid(xs, xs)
+    n = gx.size
+    down = np.zeros((n, 8), np.float32)
+    down[:, 0], down[:, 1], down[:, 2] = gx.ravel(), 3.0, gz.ravel()
+    down[:, 4] = -1.0
+    down[:, 7] = np.inf
+    diag = down.copy()                      # direction (1,-1,1): reaches the plane at t = 3 exactly on the grid point
+    diag[:, 0] -= 3.0
+    diag[:, 2] -= 3.0
+    diag[:, 3], diag[:, 5] = 1.0, 1.0
+    # Axis-parallel rays: an origin that lies on a slab plane gives 0/0 = NaN in the reference's box test, which makes it
+    # skip or keep boxes erratically (src/aabb.cpp:7-34); only the reference-order mode is expected to reproduce that.
+    want = o.intersect(down)
+    assert 0.3 < (want["prim"] >= 0).mean() < 0.9
+    assert helpers.hits_equal(g.intersect(down, api.TRAVERSE_EXACT), want).all()
+    # No zero components: both modes must agree with the reference, ties included.
+    want = o.intersect(diag)
+    assert (want["prim"] >= 0).mean() > 0.8
+    assert helpers.hits_equal(g.intersect(diag, api.TRAVERSE_EXACT), want).all()
+    assert helpers.hits_equal(g.intersect(diag, api.TRAVERSE_FAST), want).all()
+    g.close()
+
+
+@pytest.mark.parametrize("make", [lambda: synth.random_soup(1, seed=1), lambda: synth.random_soup(7, seed=2),
+                                  lambda: synth.random_soup(3000, seed=3), synth.cornell_box, lambda: synth.library_synth(n_books=800)])
+def test_traversal_parity_synthetic_scenes(make):
+    sd = make()
+    o, g = orc.Scene(sd), api.Scene(sd)
+    prim = helpers.primary_rays(o, sample=1, step=max(1, sd.width // 64))
+    closest, shadow = helpers.recorded_rays(o, 300, seed=4)
+    rays = np.concatenate([prim, closest])
+    want = o.intersect(rays)
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_EXACT), want).all()
+    same = helpers.hits_equal(g.intersect(rays, api.TRAVERSE_FAST), want)
+    assert (~same).sum() <= max(1, len(rays) // 20000)
+    if len(shadow):
+        occ, first = o.occluded(shadow)
+        g_occ, g_first = g.occluded(shadow, api.TRAVERSE_EXACT)
+        assert np.array_equal(g_occ, occ) and np.array_equal(g_first, first)
+    g.close()
+
+
+# ------------------------------------------------------------------------------------------------ film and AOVs
+
+@pytest.mark.parametrize("name,integ", [("normal", api.INTEGRATOR_NORMAL), ("albedo", api.INTEGRATOR_ALBEDO)])
+def test_aov_film_matches_oracle_and_reference_images(veach_gpu, veach_oracle, name, integ):
+    """Camera ray, Sobol' jitter, primary hit, normal interpolation and film reconstruction: equal to the oracle up to
+    float summation order, and equal to the image the reference binary wrote (tests/golden) at the same tolerance the
+    oracle itself meets."""
+    import os
+    from conftest import GOLDEN
+    film, st = veach_gpu.render(0, 32, integrator=integ, traversal=api.TRAVERSE_EXACT)
+    assert st["paths"] == 1280 * 720 * 32 and st["closest_rays"] == st["paths"] and st["any_rays"] == 0
+    want, _ = veach_oracle.render(0, 32, integ)
+    assert np.allclose(film, want, rtol=1e-4, atol=2e-4)      # sums of ~500 weighted terms in a different order
+    z = np.load(os.path.join(GOLDEN, "veach_mis_aov.npz"))
+    stride = int(z["stride"])
+    d = np.abs(api.film_to_image(film)[::stride, ::stride] - z[name]).max(-1)
+    assert d.mean() < 5e-6 and (d > 1e-5).mean() < 2e-3 and d.max() < 0.1
+
+
+def test_film_weight_channel_is_exact_filter_sum(veach_gpu, veach_oracle):
+    """The weight channel only depends on the sample positions: check it at a sample range the oracle never rendered
+    with the path integrator (cheap AOV pass on the oracle side)."""
+    film, _ = veach_gpu.render(100, 104, integrator=api.INTEGRATOR_ALBEDO)
+    want, _ = veach_oracle.render(100, 104, orc.INTEGRATOR_ALBEDO)
+    assert np.allclose(film[..., 3], want[..., 3], rtol=1e-5, atol=1e-6)
+    assert film[:2].sum() > 0 and film[2:-2, 2:-2, 3].min() > 0    # border rows receive splats, every pixel has weight
+
+
+# ------------------------------------------------------------------------------------------------ integrator
+
+def test_per_sample_radiance_matches_oracle(veach_gpu, veach_oracle, veach_sd):
+    """Integrator::Li for individual (pixel, sample) pairs.  Tolerance: at least 99% of the samples agree to 1e-3
+    relative (most agree exactly); the rest may take a different path after a BRDF sample because device and host
+    sin/cos/pow differ in the last bits.  The mean over all samples agrees to 2%."""
+    rng = np.random.default_rng(7)
+    n = 6000
+    pix = np.stack([rng.integers(0, veach_sd.width, n), rng.integers(0, veach_sd.height, n)], 1).astype(np.int32)
+    smp = rng.integers(0, 1024, n).astype(np.uint32)
+    want = np.array([veach_oracle.li(int(p[0]), int(p[1]), int(s))["rgb"] for p, s in zip(pix, smp)])
+    want_ps = np.array([veach_oracle.pixel_sample(int(p[0]), int(p[1]), int(s)) for p, s in zip(pix[:500], smp[:500])])
+    for mode in (api.TRAVERSE_EXACT, api.TRAVERSE_FAST):
+        got, ps, st = veach_gpu.li(pix, smp, traversal=mode)
+        assert np.array_equal(ps[:500].view(np.uint32), want_ps.view(np.uint32))     # film positions are bit-exact
+        err = np.abs(got - want).max(1) / (np.abs(want).max(1) + 1e-3)
+        assert (err < 1e-3).mean() >= 0.99
+        assert (err == 0).mean() >= 0.5
+        assert abs(got.mean() - want.mean()) <= 0.02 * want.mean()
+        assert np.isfinite(got).all() and (got >= 0).all()
+
+
+def test_path_traced_image_matches_oracle(veach_gpu, veach_oracle):
+    """Converged-image criterion at equal sample sets: relMSE between the GPU film and the oracle film at 16 spp
+    (same Sobol' points, so the noise cancels) must stay below 1e-5; the ray counts agree to 0.01%."""
+    film, st = veach_gpu.render(0, 16, traversal=api.TRAVERSE_EXACT)
+    want, ost = veach_oracle.render(0, 16)
+    img, ref = api.film_to_image(film), orc.film_to_image(want)
+    assert helpers.rel_mse(img, ref) < 1e-5
+    assert abs(st["closest_rays"] - ost["closest_rays"]) <= 1e-4 * ost["closest_rays"]
+    assert abs(st["any_rays"] - ost["any_rays"]) <= 1e-4 * ost["any_rays"]
+    fast, _ = veach_gpu.render(0, 16, traversal=api.TRAVERSE_FAST)
+    assert helpers.rel_mse(api.film_to_image(fast), ref) < 1e-5
+
+
+def test_sample_ranges_add_up_and_pass_size_is_irrelevant(veach_gpu):
+    """Multi-GPU sharding relies on this: films of disjoint sample ranges sum to the film of the union, and the number
+    of samples kept in flight per pass does not change the result (both up to float summation order)."""
+    a, _ = veach_gpu.render(0, 6, samples_per_pass=3)
+    b, _ = veach_gpu.render(6, 12, samples_per_pass=6)
+    c, _ = veach_gpu.render(0, 12, samples_per_pass=5)
+    assert np.allclose(a + b, c, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("make", [synth.cornell_box, lambda: synth.grid_plane(16, 96, 80), lambda: synth.random_soup(500, seed=8, width=100, height=76)])
+def test_rendering_parity_synthetic_scenes(make):
+    sd = make()
+    o, g = orc.Scene(sd), api.Scene(sd)
+    spp = 4 if sd.width > 256 else 16
+    film, st = g.render(0, spp, traversal=api.TRAVERSE_EXACT)
+    want, ost = o.render(0, spp)
+    assert helpers.rel_mse(api.film_to_image(film), orc.film_to_image(want)) < 1e-4
+    assert np.allclose(film[..., 3], want[..., 3], rtol=1e-5, atol=1e-6)
+    assert abs(st["closest_rays"] - ost["closest_rays"]) <= 2e-3 * ost["closest_rays"] + 2
+    g.close()
+
+
+def test_work_counters_match_oracle_in_exact_mode(veach_gpu, veach_oracle):
+    """Node and triangle records fetched by the reference-order traversal are the oracle's counts for primary rays."""
+    film, st = veach_gpu.render(0, 1, integrator=api.INTEGRATOR_ALBEDO, traversal=api.TRAVERSE_EXACT, flags=api.FLAG_COUNT_WORK)
+    _, ost = veach_oracle.render(0, 1, orc.INTEGRATOR_ALBEDO)
+    assert st["nodes_fetched"] == ost["nodes_visited"] and st["tris_fetched"] == ost["tris_tested"]
+    _, fst = veach_gpu.render(0, 1, integrator=api.INTEGRATOR_ALBEDO, traversal=api.TRAVERSE_FAST, flags=api.FLAG_COUNT_WORK)
+    assert 0 < fst["nodes_fetched"] < st["nodes_fetched"]
+
+
+# ------------------------------------------------------------------------------------------------ errors
+
+def test_error_reporting(veach_gpu):
+    lib = api.hip_lib()
+    p = veach_gpu.params(5, 5)
+    film = np.zeros((724, 1284, 4), np.float32)
+    rc = lib.pt_hip_render(veach_gpu.h, C.byref(p), film.ctypes.data_as(api.c_f32p), None)
+    assert rc == -1 and b"empty sample range" in lib.pt_hip_last_error()
+    with pytest.raises(api.PtError):
+        veach_gpu.intersect(np.zeros((4, 8), np.float32), mode=7)
+    with pytest.raises(api.PtError):
+        veach_gpu.li(np.array([[5000, 1]]), np.array([0]))
+    bad = api.HostScene(synth.random_soup(5, seed=1))
+    bad.desc.n_nodes = 1          # a root that claims children beyond the node array
+    h = C.c_void_p()
+    assert lib.pt_hip_scene_create(C.byref(bad.desc), C.byref(h)) < 0
