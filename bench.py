@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Throughput of one path-traced frame on N MI355X GPUs of one node.
+
+A step is one frame: every pixel of the workload's camera, `spp` Sobol' samples per pixel per GPU, MIS path tracing,
+rendered through the C ABI (libpt_hip.so) into a device-resident film, followed for N > 1 by one RCCL reduce of the film.
+Weak scaling: rank k renders sample numbers [k*spp, (k+1)*spp), so N GPUs produce an N*spp frame.
+
+Prints one JSON line (rank 0).  value = closest-hit + any-hit queries of all ranks per second, in Mrays/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "python"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+NODE_BYTES = {"exact": 32, "fast": 64}   # node record read per visit: binary node / 2-wide node
+TRI_BYTES = 48             # leaf-order triangle record {p0, e1, e2, prim}
+# streamed bytes per unit of each kernel besides the BVH records (layouts: path-tracer_amd/csrc/kernels.h)
+UNIT_BYTES = {
+    "generate": 68 + 16 + 24,        # path state + hit written, radiance slot zeroed, 2 Sobol' dimensions x 3 table words
+    "extend": 32 + 16,               # ray read, hit written
+    "shadow": 32 + 16 + 32 * 0.5,    # ray + contribution read, radiance slot read-modify-write when unoccluded (~half)
+    "shade": 68 + 52 + 48 + 84 + 32 + 232,  # state+hit in, state out, shadow entry out, 7 Sobol' dims, radiance slot, mesh/material/light gathers
+    "film": 16 + 24 + 8,             # radiance slot, 2 Sobol' dimensions, share of the patch flush
+}
+
+
+def load_workload(name):
+    from pt_hip import synth
+    from pt_hip.scene import SceneData
+    if name == "veach-mis":
+        return SceneData.load(os.path.join(ROOT, "tests", "golden", "veach_mis_scene.npz")), "veach-mis (reference mesh, 3092 tris, 3040 emitters) 1280x720"
+    if name == "cornell-box-synth":
+        return synth.cornell_box(), "cornell-box-synth (stand-in: reference mesh not in its tree) 768x768"
+    if name == "library-synth":
+        sd = synth.library_synth()
+        return sd, "library-synth (stand-in: reference mesh not in its tree, %d tris) 1280x720" % sd.n_tris
+    raise SystemExit("unknown workload " + name)
+
+
+def cpu_baseline(sd, budget_s=15.0):
+    """The oracle (a port of the reference algorithm) on the host cores, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    cores = min(os.cpu_count() or 1, 16)
+    o = orc.Scene(sd)
+    _, st = o.render(0, 1, nthreads=cores)              # probe: 1 spp, whole frame
+    rate = st["paths"] / max(st["seconds"], 1e-6)
+    spp = int(max(1, min(64, budget_s * rate / st["paths"])))
+    _, st = o.render(0, spp, nthreads=cores)
+    rays = st["closest_rays"] + st["any_rays"]
+    return {"value": rays / st["seconds"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "whole frame, %d spp of the same workload (%.1f s)" % (spp, st["seconds"]),
+            "samples_per_s": st["paths"] / st["seconds"],
+            "ref_order_nodes_per_ray": st["nodes_visited"] / rays, "ref_order_tris_per_ray": st["tris_tested"] / rays}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("PT_BENCH_WORKLOAD", "veach-mis"))
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU")
+    ap.add_argument("--traversal", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pt_hip import api
+    from pt_hip.dist import reduce_film, spp_range_weak
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    sd, label = load_workload(a.workload)
+    scene = api.Scene(sd, device=local_rank)
+    film = torch.empty((sd.height + 4, sd.width + 4, 4), dtype=torch.float32, device="cuda:%d" % local_rank)
+    mode = api.TRAVERSE_EXACT if a.traversal == "exact" else api.TRAVERSE_FAST
+    s0, s1 = spp_range_weak(rank, a.spp)
+
+    def step():
+        st = scene.render_device(film.data_ptr(), s0, s1, traversal=mode)
+        reduce_film(film, dst=0)
+        return st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(a.steps)]
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(sum(s["closest_rays"] + s["any_rays"] for s in stats)), float(sum(s["paths"] for s in stats))],
+                     dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+    rays_total, paths_total = float(t[1]), float(t[2])
+
+    if rank == 0:
+        # per-kernel device time from HIP events recorded on the launch stream inside the timed region
+        kms = {k: sum(s["kernel_ms"].get(k, 0.0) for s in stats) for k in api.KERNEL_NAMES[:5]}
+        kn = {k: sum(s["kernel_launches"].get(k, 0) for s in stats) for k in api.KERNEL_NAMES[:5]}
+        dominant = max(kms, key=kms.get)
+        # average BVH records per ray of each traversal kernel from an instrumented (untimed) pass over 8 spp
+        cst = scene.render_device(film.data_ptr(), 0, min(8, a.spp), traversal=mode, flags=api.FLAG_COUNT_WORK)
+        units = {"generate": sum(s["paths"] for s in stats), "film": sum(s["paths"] for s in stats),
+                 "extend": sum(s["closest_rays"] - s["paths"] for s in stats), "shadow": sum(s["any_rays"] for s in stats),
+                 "shade": sum(s["closest_rays"] for s in stats)}   # upper bound: misses leave the queue before shading
+        cunits = {"generate": cst["paths"], "extend": cst["closest_rays"] - cst["paths"], "shadow": cst["any_rays"]}
+        per_unit = dict(UNIT_BYTES)
+        bvh = {}
+        for k in ("generate", "extend", "shadow"):
+            n_node = cst["nodes_fetched"][k] / max(cunits[k], 1)
+            n_tri = cst["tris_fetched"][k] / max(cunits[k], 1)
+            bvh[k] = {"nodes_per_ray": n_node, "tris_per_ray": n_tri}
+            per_unit[k] += NODE_BYTES[a.traversal] * n_node + TRI_BYTES * n_tri
+        achieved = units[dominant] * per_unit[dominant] / (kms[dominant] * 1e-3) / 1e9 if kms[dominant] > 0 else 0.0
+        out = {
+            "metric": "Mrays/s", "value": rays_total / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if "synth" in a.workload else "reference mesh, no textures",
+            "config": {"workload": label, "integrator": "MIS path tracer, 32 bounces, Sobol'", "spp_per_gpu": a.spp,
+                       "traversal": a.traversal, "parallelism": "spp-range x%d + 1 film reduce" % world},
+            "samples_per_s": paths_total / dt,
+            "rays_per_path": rays_total / max(paths_total, 1.0),
+            "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
+            "kernel_launches_per_step": {k: v / a.steps for k, v in kn.items()},
+            "bvh_records_per_ray": bvh,
+            "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_unit": per_unit[dominant], "units_per_launch": units[dominant] / max(kn[dominant], 1),
+                         "avg_launch_ms": kms[dominant] / max(kn[dominant], 1)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -141,8 +141,10 @@ typedef struct pt_stats {
     uint64_t closest_rays;    /* closest-hit queries (Scene::rayIntersect(ray, its)) */
     uint64_t any_rays;        /* any-hit queries (Scene::unocculded) */
     uint64_t exact_retraces;  /* FAST-mode rays re-traced in EXACT mode */
-    uint64_t nodes_fetched;   /* BVH node records read by all traversals (PT_FLAG_COUNT_WORK only) */
-    uint64_t tris_fetched;    /* triangle records read by all traversals (PT_FLAG_COUNT_WORK only) */
+    /* PT_FLAG_COUNT_WORK only: BVH node records and triangle records read by the traversals launched from the
+     * generate, extend and shadow kernels (index 0, 1, 2) */
+    uint64_t nodes_fetched[3];
+    uint64_t tris_fetched[3];
     double   seconds;         /* wall time of the call, device work included */
     /* per-kernel device time (HIP events on the launch stream) and launch counts */
     double   kernel_ms[PT_MAX_KERNEL_STATS];

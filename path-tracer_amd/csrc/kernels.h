@@ -41,12 +41,13 @@ struct PassArgs {
     float* list_pixel_sample;
 };
 
-// counters[0] = entries in the next path queue, [1] = entries in the shadow queue, [2] = exact re-traces,
-// [4..5] = node records fetched (u64), [6..7] = triangle records fetched (u64); the last two only in counting builds
+// counters[0] = entries in the next path queue, [1] = entries in the shadow queue, [2] = exact re-traces.
+// Counting builds only: for kernel class k (0 generate, 1 extend, 2 shadow) the u64 at word 4 + 4k holds the node
+// records fetched and the u64 at word 6 + 4k the triangle records fetched.
 struct Counters {
     uint32_t* v;
 };
-constexpr int kCounterWords = 8;
+constexpr int kCounterWords = 16;
 
 PTD uint32_t lane_id() { return __lane_id(); }
 
@@ -85,9 +86,10 @@ PTD bool trace_any(const DevScene& sc, int traversal, const RayD& ray, uint32_t*
 }
 
 // add a wave's work counters to the global 64-bit totals (counting builds only)
-PTD void flush_counts(const NoCount&, uint32_t*) {}
-PTD void flush_counts(const Count& c, uint32_t* words) {
+PTD void flush_counts(const NoCount&, uint32_t*, int) {}
+PTD void flush_counts(const Count& c, uint32_t* words, int kernel_class) {
     if (!words) return;
+    words += 4 * kernel_class;
     uint32_t n = c.nodes, t = c.tris;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene sc, const float4*
         trace_closest(sc, mode, ray, h, s_stack + threadIdx.x, counters ? counters + 2 : nullptr, wc);
         hits[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
     }
-    flush_counts(wc, counters);
+    flush_counts(wc, counters, 1);
 }
 
 template <class C>
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded(DevScene sc, const float4* 
         occ[i] = hit ? 1 : 0;
         if (first_prim) first_prim[i] = hit ? fp : -1;
     }
-    flush_counts(wc, counters);
+    flush_counts(wc, counters, 2);
 }
 
 // ------------------------------------------------------------------------------------------------ generate + first extend
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
     } else if (slot < pa.n_slots) {
         lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    flush_counts(wc, cnt.v);
+    flush_counts(wc, cnt.v, 0);
     const uint32_t dst = wave_alloc(alive, cnt.v + 0);
     if (alive) {
         q.a[dst] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathQ q, uint32_
         trace_closest(sc, traversal, ray, h, s_stack + threadIdx.x, cnt.v + 2, wc);
         q.hit[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
     }
-    flush_counts(wc, cnt.v);
+    flush_counts(wc, cnt.v, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ shade
@@ -371,76 +373,114 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, ShadowQ sh, uint
             lbuf[slot] = L;
         }
     }
-    flush_counts(wc, cnt.v);
+    flush_counts(wc, cnt.v, 2);
 }
 
 // ------------------------------------------------------------------------------------------------ film
 
-// ImageBlock::put for the whole-image block (src/block.cpp:60-95): every sample is splatted with the tabulated
-// Gaussian over [ceil(p-2), floor(p+2)]^2 around its film position p = pixelSample + border.  One workgroup owns a
-// 16x16 pixel region (2x2 tiles), accumulates its samples into a 20x20 RGBA patch in LDS and adds the patch to the
-// film once.
+// ImageBlock::put (src/block.cpp:60-95) for all samples of a pass.  A sample at block-local position p (the reference
+// splats into 32x32 block images first, src/main.cpp:54-74, so positions and weights are taken relative to the block)
+// adds value * wx * wy to the pixels [ceil(p-2), floor(p+2)]^2 with w = table[int(|pixel - p| * 16)].
+//
+// One workgroup owns a 16x16 pixel region (2x2 tiles, always inside one 32x32 block).  Per sample number the 256
+// threads first publish their sample in LDS as {wx[4], wy[4], value*wx[4]} for the four film columns/rows it can reach
+// with non-zero weight (pixel+1 .. pixel+4 in film coordinates; the table is 0 from distance 2 on), then every film
+// pixel of the 20x20 patch gathers its up to 4x4 contributing samples into registers: no atomics in the loop, and a
+// fixed summation order inside the region.  The patch is added to the film once at the end.
+constexpr int kFilmRec = 20;     // floats per published sample: wy[4], wx[4], r*wx[4], g*wx[4], b*wx[4]
+constexpr int kFilmStride = 21;  // odd record stride: neighbouring samples fall into different LDS banks
+
 __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const float4* lbuf, float* film) {
-    __shared__ float s_patch[20 * 20 * 4];
-    for (int k = threadIdx.x; k < 20 * 20 * 4; k += 256) s_patch[k] = 0.0f;
-    __syncthreads();
+    __shared__ float s_rec[256 * kFilmStride];
     const uint32_t regions_x = (pa.tiles_x + 1u) / 2u;
     const uint32_t rx = blockIdx.x % regions_x, ry = blockIdx.x / regions_x;
     const uint32_t sub = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t tx = 2u * rx + (sub & 1u), ty = 2u * ry + (sub >> 1);
     const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
-    if (tx < pa.tiles_x && ty < pa.tiles_y && px < sc.cam.width && py < sc.cam.height) {
-        const uint32_t tile = ty * pa.tiles_x + tx;
-        for (uint32_t s = 0; s < pa.spp_pass; ++s) {
+    const bool inside = tx < pa.tiles_x && ty < pa.tiles_y && px < sc.cam.width && py < sc.cam.height;
+    const uint32_t tile = ty * pa.tiles_x + tx;
+    // source pixel index inside the region: (sx, sy) in [0,16)^2
+    const int sxp = int(px - 16u * rx), syp = int(py - 16u * ry);
+    const int bx = int(px & ~31u), by = int(py & ~31u);
+    const float bw = float(min(32, int(sc.cam.width) - bx)), bh = float(min(32, int(sc.cam.height) - by));
+    float* my = s_rec + (syp * 16 + sxp) * kFilmStride;
+
+    // the (up to) two patch pixels this thread accumulates: q0 = tid, q1 = tid + 256 (< 400)
+    float acc[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    for (uint32_t s = 0; s < pa.spp_pass; ++s) {
+        float rec[kFilmRec];
+#pragma unroll
+        for (int k = 0; k < kFilmRec; ++k) rec[k] = 0.0f;
+        if (inside) {
             const uint32_t slot = ((tile * pa.spp_pass + s) << 6) + lane;
             const float4 L = lbuf[slot];
             Sampler smp;
             smp.start(sc, pa.frame_tab + size_t(s) * 1024u, px, py, 2);
             const V2 j = smp.pixel2();
-            // The reference splats into a 32x32 block image first (src/main.cpp:54-74), so positions and filter weights
-            // are evaluated in block-local coordinates: (sample - block offset) + border.
-            const int bx = int(px & ~31u), by = int(py & ~31u);
             const float qx = (float(int(px)) + j.x) - float(bx), qy = (float(int(py)) + j.y) - float(by);
             // ImageBlock::put drops a sample whose rounded position leaves its block (src/block.cpp:67-71); that happens
             // when pixel + jitter rounds up to the next integer in the last column or row of a block
-            const float sx = float(min(32, int(sc.cam.width) - bx)), sy = float(min(32, int(sc.cam.height) - by));
-            if (qx < 0.0f || qx >= sx || qy < 0.0f || qy >= sy) continue;
-            const float lx = qx + 2.0f, ly = qy + 2.0f;
-            const int x0 = int(ceilf(lx - 2.0f)), x1 = int(floorf(lx + 2.0f));
-            const int y0 = int(ceilf(ly - 2.0f)), y1 = int(floorf(ly + 2.0f));
-            float wx[5], wy[5];
+            if (!(qx < 0.0f || qx >= bw || qy < 0.0f || qy >= bh)) {
+                const float lx = qx + 2.0f, ly = qy + 2.0f;  // block-local film coordinates (2-pixel border)
+                const int x0 = int(ceilf(lx - 2.0f)), x1 = int(floorf(lx + 2.0f));
+                const int y0 = int(ceilf(ly - 2.0f)), y1 = int(floorf(ly + 2.0f));
+                // film columns pixel+1 .. pixel+4 in block-local film coordinates
+                const int cx = int(px) - bx + 1, cy = int(py) - by + 1;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                wx[k] = sc.filter[min(int(fabsf(float(x0 + k) - lx) * 16.0f), 32)];
-                wy[k] = sc.filter[min(int(fabsf(float(y0 + k) - ly) * 16.0f), 32)];
+                for (int k = 0; k < 4; ++k) {
+                    const int x = cx + k, y = cy + k;
+                    const float wx = (x >= x0 && x <= x1) ? sc.filter[min(int(fabsf(float(x) - lx) * 16.0f), 32)] : 0.0f;
+                    const float wy = (y >= y0 && y <= y1) ? sc.filter[min(int(fabsf(float(y) - ly) * 16.0f), 32)] : 0.0f;
+                    rec[k] = wy;
+                    rec[4 + k] = wx;
+                    rec[8 + k] = L.x * wx;
+                    rec[12 + k] = L.y * wx;
+                    rec[16 + k] = L.z * wx;
+                }
             }
-            // block-local film index -> patch index (the patch starts at film coordinate 16 * region)
-            const int ox = bx + x0 - int(16u * rx), oy = by + y0 - int(16u * ry);
+        }
+        __syncthreads();  // previous iteration's gathers are done
 #pragma unroll
-            for (int yy = 0; yy < 5; ++yy) {
-                if (y0 + yy > y1) break;
+        for (int k = 0; k < kFilmRec; ++k) my[k] = rec[k];
+        __syncthreads();
 #pragma unroll
-                for (int xx = 0; xx < 5; ++xx) {
-                    if (x0 + xx > x1) break;
-                    float* p = s_patch + ((oy + yy) * 20 + (ox + xx)) * 4;
-                    atomicAdd(p + 0, L.x * wx[xx] * wy[yy]);
-                    atomicAdd(p + 1, L.y * wx[xx] * wy[yy]);
-                    atomicAdd(p + 2, L.z * wx[xx] * wy[yy]);
-                    atomicAdd(p + 3, 1.0f * wx[xx] * wy[yy]);
+        for (int r = 0; r < 2; ++r) {
+            const int q = int(threadIdx.x) + 256 * r;
+            if (q < 400) {
+                const int u = q % 20, v = q / 20;  // patch pixel; patch origin = film coordinate 16 * region
+                // a source pixel (sx, sy) reaches patch columns sx+1 .. sx+4, i.e. column u gets offset k = u - sx - 1
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    const int sy = v - 1 - ky;
+                    if (sy < 0 || sy > 15) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const int sx = u - 1 - kx;
+                        if (sx < 0 || sx > 15) continue;
+                        const float* src = s_rec + (sy * 16 + sx) * kFilmStride;
+                        const float wy = src[ky];
+                        acc[r][0] += src[8 + kx] * wy;   // (value * wx) * wy, as in src/block.cpp:90
+                        acc[r][1] += src[12 + kx] * wy;
+                        acc[r][2] += src[16 + kx] * wy;
+                        acc[r][3] += src[4 + kx] * wy;   // weight channel: (1 * wx) * wy
+                    }
                 }
             }
         }
     }
-    __syncthreads();
     const int fw = int(sc.cam.width) + 4, fh = int(sc.cam.height) + 4;
-    for (int k = threadIdx.x; k < 20 * 20; k += 256) {
-        const int fx = int(16u * rx) + k % 20, fy = int(16u * ry) + k / 20;
-        if (fx < fw && fy < fh && s_patch[4 * k + 3] != 0.0f) {
-            float* dst = film + (size_t(fy) * fw + fx) * 4;
-            atomicAdd(dst + 0, s_patch[4 * k + 0]);
-            atomicAdd(dst + 1, s_patch[4 * k + 1]);
-            atomicAdd(dst + 2, s_patch[4 * k + 2]);
-            atomicAdd(dst + 3, s_patch[4 * k + 3]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int q = int(threadIdx.x) + 256 * r;
+        if (q < 400) {
+            const int fx = int(16u * rx) + q % 20, fy = int(16u * ry) + q / 20;
+            if (fx < fw && fy < fh && acc[r][3] != 0.0f) {
+                float* dst = film + (size_t(fy) * fw + fx) * 4;
+                atomicAdd(dst + 0, acc[r][0]);
+                atomicAdd(dst + 1, acc[r][1]);
+                atomicAdd(dst + 2, acc[r][2]);
+                atomicAdd(dst + 3, acc[r][3]);
+            }
         }
     }
 }

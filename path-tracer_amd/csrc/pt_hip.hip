@@ -677,8 +677,10 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         HIP_TRY(hipGetLastError());
         if (st) {
             st->exact_retraces += ws.h_counters[2];
-            st->nodes_fetched += uint64_t(ws.h_counters[4]) | (uint64_t(ws.h_counters[5]) << 32);
-            st->tris_fetched += uint64_t(ws.h_counters[6]) | (uint64_t(ws.h_counters[7]) << 32);
+            for (int k = 0; k < 3; ++k) {
+                st->nodes_fetched[k] += uint64_t(ws.h_counters[4 + 4 * k]) | (uint64_t(ws.h_counters[5 + 4 * k]) << 32);
+                st->tris_fetched[k] += uint64_t(ws.h_counters[6 + 4 * k]) | (uint64_t(ws.h_counters[7 + 4 * k]) << 32);
+            }
         }
         if (int rc = tm.collect(st)) return rc;
     }

@@ -56,10 +56,12 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64), ("exact_retraces", C.c_uint64),
-                ("nodes_fetched", C.c_uint64), ("tris_fetched", C.c_uint64), ("seconds", C.c_double), ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8)]
+                ("nodes_fetched", C.c_uint64 * 3), ("tris_fetched", C.c_uint64 * 3), ("seconds", C.c_double), ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k in ("paths", "closest_rays", "any_rays", "exact_retraces", "nodes_fetched", "tris_fetched", "seconds")}
+        d = {k: getattr(self, k) for k in ("paths", "closest_rays", "any_rays", "exact_retraces", "seconds")}
+        d["nodes_fetched"] = {n: self.nodes_fetched[i] for i, n in enumerate(("generate", "extend", "shadow"))}
+        d["tris_fetched"] = {n: self.tris_fetched[i] for i, n in enumerate(("generate", "extend", "shadow"))}
         d["kernel_ms"] = {KERNEL_NAMES[i]: self.kernel_ms[i] for i in range(8) if self.kernel_launches[i]}
         d["kernel_launches"] = {KERNEL_NAMES[i]: self.kernel_launches[i] for i in range(8) if self.kernel_launches[i]}
         return d
