@@ -4,8 +4,17 @@
 //     slot = ((tile * spp_pass + s) * 64 + lane),  tile = 8x8 pixels, lane = y_in_tile * 8 + x_in_tile
 // so that a wave starts as one 8x8 pixel tile of one sample number (coherent primary rays, a wave-uniform Sobol' row).
 // Radiance is accumulated per slot in `lbuf` in the reference's order (emission, then direct light, bounce by bounce:
-// src/integrator.cpp:58-73).  Path state travels with the compacted queues: every kernel reads and writes lane-
-// contiguous float4 streams, and a path's position in the queue changes from bounce to bounce while its slot does not.
+// src/integrator.cpp:58-73).
+//
+// Queues are SHARDED: the slot range is cut into shards of kShard slots, and every shard is an independent compacting
+// queue with its own counters.  A path never leaves its shard; a kernel is launched as grid (blocks, shards) and
+// block (x, s) works on entries [x * blockDim, ...) of shard s.  One device-wide counter would serialise every wave
+// of a launch on a single address (measured: ~90 returning atomics per microsecond per address, which made queue
+// allocation the bottleneck of the first version); with a few thousand shards each counter sees at most
+// kShard / 64 atomics per launch, and launches need no exact global count -- only the largest shard fill.
+//
+// Per bounce:  shade (hit list -> next paths + shadow rays) -> shadow (any-hit, adds direct light) + extend (closest
+// hit of the next paths, writes the next hit list: misses are dropped here, so shade only sees lanes with work).
 #pragma once
 
 #include "shade.h"
@@ -13,18 +22,28 @@
 
 namespace ptd {
 
+constexpr uint32_t kShard = 4096;  // slots per shard; a multiple of every block size used below
+
 struct PathQ {
-    float4* a;       // {o.x, o.y, o.z, d.x}
-    float4* b;       // {d.y, d.z, T.x, T.y}
-    float4* c;       // {T.z, brdfPdf, bits(px | py << 16), bits(dim | bounce << 10 | frame << 16)}
-    uint32_t* slot;  // sample slot
-    float4* hit;     // {bits(prim), t, u, v} written by the extend step
+    float4* a;        // {o.x, o.y, o.z, d.x}
+    float4* b;        // {d.y, d.z, T.x, T.y}
+    float4* c;        // {T.z, brdfPdf, bits(px | py << 16), bits(dim | bounce << 10 | frame << 16)}
+    uint32_t* slot;   // sample slot
+    uint32_t* count;  // [shard] entries in use
+};
+
+struct HitQ {
+    float4* h0;       // {bits(path index inside the shard), bits(prim), u, v}
+    float4* h1;       // {bits(px | py << 16), bits(dim | bounce << 10 | frame << 16), t, 0}  (copied so that shade can
+                      //  start its Sobol' and triangle-record reads without waiting for the path state)
+    uint32_t* count;  // [shard]
 };
 
 struct ShadowQ {
-    float4* a;  // {o.x, o.y, o.z, d.x}
-    float4* b;  // {d.y, d.z, tmax, bits(slot)}
-    float4* c;  // {contribution rgb (throughput already applied), 0}
+    float4* a;        // {o.x, o.y, o.z, d.x}
+    float4* b;        // {d.y, d.z, tmax, bits(slot)}
+    float4* c;        // {contribution rgb (throughput already applied), 0}
+    uint32_t* count;  // [shard]
 };
 
 struct PassArgs {
@@ -41,13 +60,9 @@ struct PassArgs {
     float* list_pixel_sample;
 };
 
-// counters[0] = entries in the next path queue, [1] = entries in the shadow queue, [2] = exact re-traces.
-// Counting builds only: for kernel class k (0 generate, 1 extend, 2 shadow) the u64 at word 4 + 4k holds the node
-// records fetched and the u64 at word 6 + 4k the triangle records fetched.
-struct Counters {
-    uint32_t* v;
-};
-constexpr int kCounterWords = 16;
+// misc[0] = exact re-traces.  Counting builds only: for kernel class k (0 generate, 1 extend, 2 shadow) the u64 at
+// word 4 + 4k holds the node records fetched and the u64 at word 6 + 4k the triangle records fetched.
+constexpr int kMiscWords = 16;
 
 PTD uint32_t lane_id() { return __lane_id(); }
 
@@ -87,9 +102,9 @@ PTD bool trace_any(const DevScene& sc, int traversal, const RayD& ray, uint32_t*
 
 // add a wave's work counters to the global 64-bit totals (counting builds only)
 PTD void flush_counts(const NoCount&, uint32_t*, int) {}
-PTD void flush_counts(const Count& c, uint32_t* words, int kernel_class) {
-    if (!words) return;
-    words += 4 * kernel_class;
+PTD void flush_counts(const Count& c, uint32_t* misc, int kernel_class) {
+    if (!misc) return;
+    misc += 4 * kernel_class;
     uint32_t n = c.nodes, t = c.tris;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -97,8 +112,8 @@ PTD void flush_counts(const Count& c, uint32_t* words, int kernel_class) {
         t += uint32_t(__shfl_xor(int(t), off));
     }
     if (lane_id() == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(words + 4), (unsigned long long)n);
-        atomicAdd(reinterpret_cast<unsigned long long*>(words + 6), (unsigned long long)t);
+        atomicAdd(reinterpret_cast<unsigned long long*>(misc + 4), (unsigned long long)n);
+        atomicAdd(reinterpret_cast<unsigned long long*>(misc + 6), (unsigned long long)t);
     }
 }
 
@@ -106,7 +121,7 @@ PTD void flush_counts(const Count& c, uint32_t* words, int kernel_class) {
 
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_intersect(DevScene sc, const float4* rays, uint32_t n, float4* hits, int mode,
-                                                       uint32_t* counters) {
+                                                       uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     C wc;
@@ -114,15 +129,15 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene sc, const float4*
         const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
         const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
         HitD h;
-        trace_closest(sc, mode, ray, h, s_stack + threadIdx.x, counters ? counters + 2 : nullptr, wc);
+        trace_closest(sc, mode, ray, h, s_stack + threadIdx.x, misc, wc);
         hits[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
     }
-    flush_counts(wc, counters, 1);
+    flush_counts(wc, misc, 1);
 }
 
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_occluded(DevScene sc, const float4* rays, uint32_t n, uint8_t* occ, int32_t* first_prim,
-                                                      int mode, uint32_t* counters) {
+                                                      int mode, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     C wc;
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded(DevScene sc, const float4* 
         occ[i] = hit ? 1 : 0;
         if (first_prim) first_prim[i] = hit ? fp : -1;
     }
-    flush_counts(wc, counters, 2);
+    flush_counts(wc, misc, 2);
 }
 
 // ------------------------------------------------------------------------------------------------ generate + first extend
@@ -146,11 +161,13 @@ __global__ __launch_bounds__(kBlock) void k_occluded(DevScene sc, const float4* 
 // renderBlock's per-sample prologue (src/main.cpp:63-68): startPixelSample, pixelSample = pixel + samplePixel2D(),
 // then the camera ray and the first Scene::rayIntersect of PathIntegrator::Li (src/integrator.cpp:46-53).
 // For the two AOV integrators (src/integrator.cpp:20-43) the result is final and goes straight to lbuf.
+// Paths that hit something enter path queue `q` and hit list `hq` at the same position of their slot's shard.
 template <class C>
-__global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, PathQ q, float4* lbuf, Counters cnt) {
+__global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, PathQ q, HitQ hq, float4* lbuf, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     C wc;
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t shard = slot / kShard;  // wave-uniform: kShard is a multiple of the block size
     bool valid = slot < pa.n_slots;
     uint32_t px = 0, py = 0, frame = 0;
     if (valid) {
@@ -171,54 +188,72 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
     HitD h{-1, 0.0f, 0.0f, 0.0f};
     RayD ray{};
     if (valid) {
-        Sampler smp;
-        smp.start(sc, pa.frame_tab + size_t(frame) * 1024u, px, py, 2);
-        const V2 j = smp.pixel2();
+        const V2 j = pixel_jitter(sc, pa.frame_tab + size_t(frame) * 1024u, px, py);
         const V2 ps{float(int(px)) + j.x, float(int(py)) + j.y};
         if (pa.list_pixel_sample) {
             pa.list_pixel_sample[2 * size_t(slot)] = ps.x;
             pa.list_pixel_sample[2 * size_t(slot) + 1] = ps.y;
         }
         camera_ray(sc.cam, ps, ray.o, ray.d, ray.tmin, ray.tmax);
-        alive = trace_closest(sc, pa.traversal, ray, h, s_stack + threadIdx.x, cnt.v + 2, wc);
+        alive = trace_closest(sc, pa.traversal, ray, h, s_stack + threadIdx.x, misc, wc);
         V3 out = mk3(0.0f);
         if (alive && pa.integrator != 0) {
-            Surf it;
-            complete(sc, uint32_t(h.prim), h.u, h.v, it);
-            out = (pa.integrator == 1) ? it.n : base_color(sc, load_mat(sc, it.prim), it.uv);
+            TriRec t;
+            t.load(sc, uint32_t(h.prim));
+            if (pa.integrator == 1) {
+                Surf it;
+                complete(t, h.u, h.v, it);
+                out = it.n;
+            } else {
+                out = surface_material(sc, t, uint32_t(h.prim), h.u, h.v).kd;
+            }
             alive = false;
         }
         lbuf[slot] = make_float4(out.x, out.y, out.z, 0.0f);
     } else if (slot < pa.n_slots) {
         lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    flush_counts(wc, cnt.v, 0);
-    const uint32_t dst = wave_alloc(alive, cnt.v + 0);
+    flush_counts(wc, misc, 0);
+    const uint32_t local = wave_alloc(alive, q.count + shard);
     if (alive) {
+        const size_t dst = size_t(shard) * kShard + local;
+        const uint32_t pix = px | (py << 16), meta = 2u | (0u << 10) | (frame << 16);
         q.a[dst] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
         q.b[dst] = make_float4(ray.d.y, ray.d.z, 1.0f, 1.0f);
-        q.c[dst] = make_float4(1.0f, 0.0f, as_f(px | (py << 16)), as_f(2u | (0u << 10) | (frame << 16)));
+        q.c[dst] = make_float4(1.0f, 0.0f, as_f(pix), as_f(meta));
         q.slot[dst] = slot;
-        q.hit[dst] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+        hq.h0[dst] = make_float4(as_f(local), as_f(uint32_t(h.prim)), h.u, h.v);
+        hq.h1[dst] = make_float4(as_f(pix), as_f(meta), h.t, 0.0f);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ extend (bounce >= 1)
 
 // Scene::rayIntersect for rays spawned by Intersection::genRay (src/shape.cpp:186-189): tmin 0, tmax +inf.
+// Hits are appended to the shard's hit list; a miss ends the path (src/integrator.cpp:53) and is simply not listed.
 template <class C>
-__global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathQ q, uint32_t n, int traversal, Counters cnt) {
+__global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathQ q, HitQ hq, int traversal, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t shard = blockIdx.y;
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    const size_t i = size_t(shard) * kShard + j;
     C wc;
-    if (i < n) {
+    bool found = false;
+    HitD h{-1, 0.0f, 0.0f, 0.0f};
+    float4 c{};
+    if (j < q.count[shard]) {
         const float4 a = q.a[i], b = q.b[i];
+        c = q.c[i];
         const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
-        HitD h;
-        trace_closest(sc, traversal, ray, h, s_stack + threadIdx.x, cnt.v + 2, wc);
-        q.hit[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+        found = trace_closest(sc, traversal, ray, h, s_stack + threadIdx.x, misc, wc);
     }
-    flush_counts(wc, cnt.v, 1);
+    flush_counts(wc, misc, 1);
+    const uint32_t local = wave_alloc(found, hq.count + shard);
+    if (found) {
+        const size_t dst = size_t(shard) * kShard + local;
+        hq.h0[dst] = make_float4(as_f(j), as_f(uint32_t(h.prim)), h.u, h.v);
+        hq.h1[dst] = make_float4(c.z, c.w, h.t, 0.0f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ shade
@@ -226,129 +261,139 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathQ q, uint32_
 // One iteration of the loop body of PathIntegrator::Li after the intersection (src/integrator.cpp:55-103) plus
 // sampleLd up to the visibility test (src/integrator.cpp:109-141): the shadow ray and its already-weighted
 // contribution go to the shadow queue, the continued path to the next path queue.
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, PathQ in, uint32_t n, PathQ out, ShadowQ sh, float4* lbuf,
-                                                Counters cnt) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+//
+// Memory reads are arranged in three dependent levels: (1) the hit-list entry; (2) the path state, the triangle's
+// shading record and the Sobol' window (all addressed from the entry); (3) the record of the light chosen by the first
+// Sobol' value.
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq, PathQ in, PathQ out, ShadowQ sh, float4* lbuf) {
+    const uint32_t shard = blockIdx.y;
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    const size_t sbase = size_t(shard) * kShard;
     bool cont = false, want_shadow = false;
     float4 na{}, nb{}, nc{}, sa{}, sb{}, sc4{};
     uint32_t slot = 0;
-    if (i < n) {
-        const float4 hit = in.hit[i];
-        const int32_t prim = int32_t(as_u(hit.x));
-        if (prim >= 0) {  // a miss ends the path (src/integrator.cpp:53)
-            const float4 a = in.a[i], b = in.b[i], c = in.c[i];
-            slot = in.slot[i];
-            const V3 ro{a.x, a.y, a.z}, rd{a.w, b.x, b.y};
-            V3 T{b.z, b.w, c.x};
-            const float brdfPdf = c.y;
-            const uint32_t pix = as_u(c.z), meta = as_u(c.w);
-            const uint32_t frame = meta >> 16;
-            int bounce = int((meta >> 10) & 63u);
-            Sampler smp;
-            smp.start(sc, pa.frame_tab + size_t(frame) * 1024u, pix & 0xffffu, pix >> 16, int(meta & 1023u));
+    if (j < hq.count[shard]) {
+        const float4 h0 = hq.h0[sbase + j], h1 = hq.h1[sbase + j];
+        const size_t pi = sbase + as_u(h0.x);
+        const uint32_t prim = as_u(h0.y);
+        const uint32_t pix = as_u(h1.x), meta = as_u(h1.y);
+        const uint32_t frame = meta >> 16;
+        int bounce = int((meta >> 10) & 63u);
+        // level 2 reads
+        const float4 a = in.a[pi], b = in.b[pi], c = in.c[pi];
+        slot = in.slot[pi];
+        TriRec tr;
+        tr.load(sc, prim);
+        Sampler smp;
+        smp.start(sc, pa.frame_tab + size_t(frame) * 1024u, pix & 0xffffu, pix >> 16, int(meta & 1023u));
+        // level 3: the light record depends on the first Sobol' value only
+        LightRec lr;
+        float u1 = 0.0f;
+        if (sc.n_lights != 0u) {
+            u1 = smp.s1();
+            uint32_t li = uint32_t(int(u1 * float(sc.n_lights)));  // include/pt/light.h:58-60
+            if (li >= sc.n_lights) li = sc.n_lights - 1u;          // the reference would throw here; clamp instead
+            lr.load(sc, li);
+        }
 
-            Surf it;
-            complete(sc, uint32_t(prim), hit.z, hit.w, it);
-            const V3 wo = -rd;
-            const Mat m = load_mat(sc, it.prim);
-            const V3 kd = base_color(sc, m, it.uv);
+        const V3 ro{a.x, a.y, a.z}, rd{a.w, b.x, b.y};
+        V3 T{b.z, b.w, c.x};
+        const float brdfPdf = c.y;
+        Surf it;
+        complete(tr, h0.z, h0.w, it);
+        const V3 wo = -rd;
+        const Mat m = surface_material(sc, tr, prim, h0.z, h0.w);
 
-            // emitted radiance with MIS against light sampling (src/integrator.cpp:58-69)
-            const int32_t lid = sc.light_id[it.prim];
-            if (lid >= 0) {
-                const DevLight& l = sc.lights[lid];
-                const V3 Le = dot(it.n, wo) > 0.0f ? V3{l.lemit[0], l.lemit[1], l.lemit[2]} : mk3(0.0f);
-                V3 add;
-                if (bounce == 0) {
-                    add = cmul(T, Le);
-                } else {
-                    float lpdf = light_pdf(l, it.p, it.n, ro, rd);
-                    lpdf *= 1.0f / float(sc.n_lights);
-                    const float w = power_heuristic(brdfPdf, lpdf);
-                    add = w * cmul(T, Le);
-                }
-                float4 L = lbuf[slot];
-                L.x += add.x;
-                L.y += add.y;
-                L.z += add.z;
-                lbuf[slot] = L;
-            }
-
-            // light sampling (src/integrator.cpp:109-141)
-            if (sc.n_lights != 0u) {
-                const float u1 = smp.s1();
-                uint32_t li = uint32_t(int(u1 * float(sc.n_lights)));  // include/pt/light.h:58-60
-                if (li >= sc.n_lights) li = sc.n_lights - 1u;          // the reference would throw here; clamp instead
-                const DevLight& l = sc.lights[li];
-                const float selectPdf = 1.0f / float(sc.n_lights);
-                const LiSample ls = light_sample(sc, l, it.p, it.n, smp.s2());
-                if (ls.pdfDir != 0.0f) {
-                    // Scene::unocculded (src/scene.cpp:213-220)
-                    const V3 p0 = it.p + it.n * kEps, p1 = ls.p + ls.n * kEps;
-                    const V3 d = p1 - p0;
-                    const float dist = norm(d);
-                    const V3 sd = d / dist;
-                    const V3 f = brdf_eval(m, kd, it.n, wo, ls.wi);
-                    const float cosTheta = dot(it.n, ls.wi);
-                    const float bp = brdf_pdf(m, kd, it.n, wo, ls.wi);
-                    const float lp = ls.pdfDir * selectPdf;
-                    const float w = power_heuristic(lp, bp);
-                    const V3 Ld = w * cmul(f, ls.L) * cosTheta / lp;
-                    const V3 contrib = cmul(T, Ld);
-                    want_shadow = true;
-                    sa = make_float4(p0.x, p0.y, p0.z, sd.x);
-                    sb = make_float4(sd.y, sd.z, dist * (1 - kEps), as_f(slot));
-                    sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
-                }
-            }
-
-            // BRDF sampling; the 2-D sample is drawn before the 1-D one (src/integrator.cpp:83, right-to-left arguments)
-            const V2 u = smp.s2();
-            const float uc = smp.s1();
-            const BSample bs = brdf_sample(m, kd, it, wo, uc, u);
-            float newPdf = brdfPdf;
-            bool go = true;
-            if (bs.specular) {
-                bounce--;
-                newPdf = 1.0f;
+        // emitted radiance with MIS against light sampling (src/integrator.cpp:58-69)
+        if (tr.light_id() >= 0) {
+            const V3 Le = dot(it.n, wo) > 0.0f ? tr.lemit() : mk3(0.0f);
+            V3 add;
+            if (bounce == 0) {
+                add = cmul(T, Le);
             } else {
-                if (sqnorm(bs.f) == 0.0f || bs.pdf == 0.0f) go = false;
-                if (go) {
-                    const V3 thr = bs.f * dot(it.n, bs.wi) / bs.pdf;
-                    T = cmul(T, thr);
-                    newPdf = bs.pdf;
-                }
+                float lpdf = light_pdf(tr.inv_area(), it.p, it.n, ro, rd);
+                lpdf *= 1.0f / float(sc.n_lights);
+                const float w = power_heuristic(brdfPdf, lpdf);
+                add = w * cmul(T, Le);
             }
+            float4 L = lbuf[slot];
+            L.x += add.x;
+            L.y += add.y;
+            L.z += add.z;
+            lbuf[slot] = L;
+        }
+
+        // light sampling (src/integrator.cpp:109-141)
+        if (sc.n_lights != 0u) {
+            const float selectPdf = 1.0f / float(sc.n_lights);
+            const LiSample ls = light_sample(lr, it.p, it.n, smp.s2());
+            if (ls.pdfDir != 0.0f) {
+                // Scene::unocculded (src/scene.cpp:213-220)
+                const V3 p0 = it.p + it.n * kEps, p1 = ls.p + ls.n * kEps;
+                const V3 d = p1 - p0;
+                const float dist = norm(d);
+                const V3 sd = d / dist;
+                V3 f;
+                float bp;
+                brdf_eval_pdf(m, it.n, wo, ls.wi, f, bp);
+                const float cosTheta = dot(it.n, ls.wi);
+                const float lp = ls.pdfDir * selectPdf;
+                const float w = power_heuristic(lp, bp);
+                const V3 Ld = w * cmul(f, ls.L) * cosTheta / lp;
+                const V3 contrib = cmul(T, Ld);
+                want_shadow = true;
+                sa = make_float4(p0.x, p0.y, p0.z, sd.x);
+                sb = make_float4(sd.y, sd.z, dist * (1 - kEps), as_f(slot));
+                sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+            }
+        }
+
+        // BRDF sampling; the 2-D sample is drawn before the 1-D one (src/integrator.cpp:83, right-to-left arguments)
+        const V2 u = smp.s2();
+        const float uc = smp.s1();
+        const BSample bs = brdf_sample(m, it, wo, uc, u);
+        float newPdf = brdfPdf;
+        bool go = true;
+        if (bs.specular) {
+            bounce--;
+            newPdf = 1.0f;
+        } else {
+            if (sqnorm(bs.f) == 0.0f || bs.pdf == 0.0f) go = false;
             if (go) {
-                const V3 no = it.p + it.ng * kEps;  // Intersection::genRay (src/shape.cpp:186-189)
-                // Russian roulette (src/integrator.cpp:99-103)
-                if (maxc(T) < 1.0f && bounce > 1) {
-                    const float qq = std_max(0.0f, 1.0f - maxc(T));
-                    if (smp.s1() < qq) go = false;
-                    T = T / (1.0f - qq);
-                }
-                bounce++;
-                if (go && bounce < int(pa.max_bounce)) {
-                    cont = true;
-                    na = make_float4(no.x, no.y, no.z, bs.wi.x);
-                    nb = make_float4(bs.wi.y, bs.wi.z, T.x, T.y);
-                    nc = make_float4(T.z, newPdf, as_f(pix), as_f(uint32_t(smp.dim) | (uint32_t(bounce) << 10) | (frame << 16)));
-                }
+                const V3 thr = bs.f * dot(it.n, bs.wi) / bs.pdf;
+                T = cmul(T, thr);
+                newPdf = bs.pdf;
+            }
+        }
+        if (go) {
+            const V3 no = it.p + it.ng * kEps;  // Intersection::genRay (src/shape.cpp:186-189)
+            // Russian roulette (src/integrator.cpp:99-103)
+            if (maxc(T) < 1.0f && bounce > 1) {
+                const float qq = std_max(0.0f, 1.0f - maxc(T));
+                if (smp.s1() < qq) go = false;
+                T = T / (1.0f - qq);
+            }
+            bounce++;
+            if (go && bounce < int(pa.max_bounce)) {
+                cont = true;
+                na = make_float4(no.x, no.y, no.z, bs.wi.x);
+                nb = make_float4(bs.wi.y, bs.wi.z, T.x, T.y);
+                nc = make_float4(T.z, newPdf, as_f(pix), as_f(uint32_t(smp.dim) | (uint32_t(bounce) << 10) | (frame << 16)));
             }
         }
     }
-    const uint32_t sdst = wave_alloc(want_shadow, cnt.v + 1);
+    const uint32_t sl = wave_alloc(want_shadow, sh.count + shard);
     if (want_shadow) {
-        sh.a[sdst] = sa;
-        sh.b[sdst] = sb;
-        sh.c[sdst] = sc4;
+        sh.a[sbase + sl] = sa;
+        sh.b[sbase + sl] = sb;
+        sh.c[sbase + sl] = sc4;
     }
-    const uint32_t dst = wave_alloc(cont, cnt.v + 0);
+    const uint32_t nl = wave_alloc(cont, out.count + shard);
     if (cont) {
-        out.a[dst] = na;
-        out.b[dst] = nb;
-        out.c[dst] = nc;
-        out.slot[dst] = slot;
+        out.a[sbase + nl] = na;
+        out.b[sbase + nl] = nb;
+        out.c[sbase + nl] = nc;
+        out.slot[sbase + nl] = slot;
     }
 }
 
@@ -356,11 +401,13 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, PathQ i
 
 // Visibility test of sampleLd (src/integrator.cpp:124-126): unoccluded rays add their contribution.
 template <class C>
-__global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, ShadowQ sh, uint32_t n, int traversal, float4* lbuf, Counters cnt) {
+__global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, ShadowQ sh, int traversal, float4* lbuf, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t shard = blockIdx.y;
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    const size_t i = size_t(shard) * kShard + j;
     C wc;
-    if (i < n) {
+    if (j < sh.count[shard]) {
         const float4 a = sh.a[i], b = sh.b[i];
         const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
         if (!trace_any(sc, traversal, ray, s_stack + threadIdx.x, wc)) {
@@ -373,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, ShadowQ sh, uint
             lbuf[slot] = L;
         }
     }
-    flush_counts(wc, cnt.v, 2);
+    flush_counts(wc, misc, 2);
 }
 
 // ------------------------------------------------------------------------------------------------ film
@@ -414,9 +461,7 @@ __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const fl
         if (inside) {
             const uint32_t slot = ((tile * pa.spp_pass + s) << 6) + lane;
             const float4 L = lbuf[slot];
-            Sampler smp;
-            smp.start(sc, pa.frame_tab + size_t(s) * 1024u, px, py, 2);
-            const V2 j = smp.pixel2();
+            const V2 j = pixel_jitter(sc, pa.frame_tab + size_t(s) * 1024u, px, py);
             const float qx = (float(int(px)) + j.x) - float(bx), qy = (float(int(py)) + j.y) - float(by);
             // ImageBlock::put drops a sample whose rounded position leaves its block (src/block.cpp:67-71); that happens
             // when pixel + jitter rounds up to the next integer in the last column or row of a block
@@ -492,7 +537,7 @@ __global__ void k_sobol(DevScene sc, const uint32_t* frame_tab, const int32_t* x
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Sampler smp;
-    smp.start(sc, frame_tab + size_t(frame_local[i]) * 1024u, uint32_t(xy[2 * size_t(i)]), uint32_t(xy[2 * size_t(i) + 1]), 2);
+    smp.start(sc, frame_tab + size_t(frame_local[i]) * 1024u, uint32_t(xy[2 * size_t(i)]), uint32_t(xy[2 * size_t(i) + 1]), int(dim[i]));
     out[i] = smp.value(int(dim[i]));
 }
 

@@ -69,15 +69,20 @@ inline uint64_t frame_index(uint32_t m, uint64_t frame) {
 }
 
 struct Workspace {
-    uint32_t cap_slots = 0;
+    uint32_t cap_slots = 0;   // padded to whole shards
+    uint32_t n_shards = 0;
     PathQ q[2]{};
+    HitQ hq{};
     ShadowQ sh{};
     float4* lbuf = nullptr;
-    uint32_t* counters = nullptr;  // device, kCounterWords words
+    // device counters: [q0 | q1 | shadow | hit] of n_shards words each, then kMiscWords
+    uint32_t* counters = nullptr;
     uint32_t* h_counters = nullptr;  // pinned host mirror
+    uint32_t* misc = nullptr;
     uint32_t* frame_tab = nullptr;
     size_t frame_cap = 0;  // in frames
     std::vector<void*> owned;
+    size_t counter_words() const { return size_t(4) * n_shards + kMiscWords; }
 };
 
 struct EventPool {
@@ -221,31 +226,62 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
         dev.wide_root = ref_of(0);
         if (int rc = upload(s, w.data(), w.size(), &dev.wide)) return rc;
     }
-    // shading data
-    if (int rc = upload(s, d->verts, 3 * size_t(d->n_verts), &dev.verts)) return rc;
-    if (int rc = upload(s, d->normals, 3 * size_t(d->n_normals), &dev.normals)) return rc;
-    if (int rc = upload(s, d->uvs, 2 * size_t(d->n_uvs), &dev.uvs)) return rc;
-    if (int rc = upload(s, d->vi, 3 * size_t(d->n_tris), &dev.vi)) return rc;
-    if (int rc = upload(s, d->ni, d->ni ? 3 * size_t(d->n_tris) : 0, &dev.ni)) return rc;
-    if (int rc = upload(s, d->ti, d->ti ? 3 * size_t(d->n_tris) : 0, &dev.ti)) return rc;
-    if (int rc = upload(s, d->mat_id, d->n_tris, &dev.mat_id)) return rc;
-    if (int rc = upload(s, d->light_id, d->n_tris, &dev.light_id)) return rc;
+    // shading records: one 128-byte record per triangle, one 96-byte record per light
     {
-        std::vector<DevMaterial> m(d->n_mats);
-        for (uint32_t i = 0; i < d->n_mats; ++i) {
-            std::memcpy(m[i].kd, d->mats[i].kd, 12);
-            std::memcpy(m[i].ks, d->mats[i].ks, 12);
-            m[i].ns = d->mats[i].ns;
-            m[i].tex = d->mats[i].tex;
+        auto vert = [&](uint32_t prim, int k) { return d->verts + 3 * size_t(d->vi[3 * size_t(prim) + k] - 1); };
+        auto has_normals = [&](uint32_t prim) { return d->n_normals != 0 && d->ni && d->ni[3 * size_t(prim)] != 0; };
+        auto normal = [&](uint32_t prim, int k) { return d->normals + 3 * size_t(d->ni[3 * size_t(prim) + k] - 1); };
+        for (uint32_t t = 0; t < d->n_tris; ++t)
+            if (has_normals(t))
+                for (int k = 0; k < 3; ++k)
+                    if (d->ni[3 * size_t(t) + k] == 0) return fail(PT_ERR_INVALID, "face with a partial set of normal indices");
+        auto bits = [](uint32_t u) {
+            float f;
+            std::memcpy(&f, &u, 4);
+            return f;
+        };
+        auto pack_geometry = [&](uint32_t prim, float4* o) {  // v0 v1 v2 n0 n1 n2 in 4.5 float4
+            const float *a = vert(prim, 0), *b = vert(prim, 1), *c = vert(prim, 2);
+            float n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (has_normals(prim))
+                for (int k = 0; k < 3; ++k) std::memcpy(n + 3 * k, normal(prim, k), 12);
+            o[0] = make_float4(a[0], a[1], a[2], b[0]);
+            o[1] = make_float4(b[1], b[2], c[0], c[1]);
+            o[2] = make_float4(c[2], n[0], n[1], n[2]);
+            o[3] = make_float4(n[3], n[4], n[5], n[6]);
+            o[4] = make_float4(n[7], n[8], 0.0f, 0.0f);
+        };
+        std::vector<float4> trec(size_t(kTriRecVec4) * d->n_tris);
+        for (uint32_t t = 0; t < d->n_tris; ++t) {
+            float4* o = &trec[size_t(kTriRecVec4) * t];
+            pack_geometry(t, o);
+            uint32_t flags = has_normals(t) ? kTriHasNormals : 0u;
+            if (d->n_uvs != 0 && d->ti && d->ti[3 * size_t(t)] != 0) flags |= kTriHasUvs;
+            const int32_t lid = d->light_id[t];
+            o[4].z = bits(flags);
+            o[4].w = bits(uint32_t(lid));
+            const pt_material& m = d->mats[d->mat_id[t]];
+            o[5] = make_float4(m.kd[0], m.kd[1], m.kd[2], m.ns);
+            o[6] = make_float4(m.ks[0], m.ks[1], m.ks[2], bits(uint32_t(m.tex)));
+            o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (lid >= 0) {
+                const pt_light& l = d->lights[lid];
+                o[7] = make_float4(l.lemit[0], l.lemit[1], l.lemit[2], float(1.0 / double(l.area)));
+            }
         }
-        if (int rc = upload(s, m.data(), m.size(), &dev.mats)) return rc;
-        std::vector<DevLight> l(d->n_lights);
+        if (int rc = upload(s, trec.data(), trec.size(), &dev.trec)) return rc;
+        std::vector<float4> lrec(size_t(kLightRecVec4) * d->n_lights);
         for (uint32_t i = 0; i < d->n_lights; ++i) {
-            l[i].tri = d->lights[i].tri;
-            std::memcpy(l[i].lemit, d->lights[i].lemit, 12);
-            l[i].inv_area = float(1.0 / double(d->lights[i].area));
+            const pt_light& l = d->lights[i];
+            float4* o = &lrec[size_t(kLightRecVec4) * i];
+            pack_geometry(l.tri, o);
+            o[4].z = bits(has_normals(l.tri) ? kTriHasNormals : 0u);
+            o[4].w = float(1.0 / double(l.area));
+            o[5] = make_float4(l.lemit[0], l.lemit[1], l.lemit[2], 0.0f);
         }
-        if (int rc = upload(s, l.data(), l.size(), &dev.lights)) return rc;
+        if (int rc = upload(s, lrec.data(), lrec.size(), &dev.lrec)) return rc;
+        if (int rc = upload(s, d->uvs, 2 * size_t(d->n_uvs), &dev.uvs)) return rc;
+        if (int rc = upload(s, d->ti, d->ti ? 3 * size_t(d->n_tris) : 0, &dev.ti)) return rc;
         std::vector<DevTexture> t(d->n_textures);
         std::vector<float> texels;
         for (uint32_t i = 0; i < d->n_textures; ++i) {
@@ -258,8 +294,6 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
         if (int rc = upload(s, texels.data(), texels.size(), &dev.tex_data)) return rc;
     }
     dev.n_tris = d->n_tris;
-    dev.n_normals = d->ni ? d->n_normals : 0;
-    dev.n_uvs = d->ti ? d->n_uvs : 0;
     dev.n_lights = d->n_lights;
     // camera
     std::memcpy(dev.cam.s2c, d->camera.sample2camera, 64);
@@ -271,23 +305,23 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     s->width = d->camera.width;
     s->height = d->camera.height;
     // Sobol' tables.  scale and m as in SobolSampler (src/sampler.cpp:89-100); for a power of two log2int is exact.
+    // X[px][dim] / Y[py][dim]: the Sobol' word of dimension dim for the index bits that pixel column px / row py
+    // contributes through sobolIntervalToIndex (src/sampler.cpp:29-33).
     {
         const uint32_t scale = uint32_t(round_up_pow2(int32_t(std::max(d->camera.width, d->camera.height))));
         uint32_t m = 0;
         while ((1u << m) < scale) ++m;
         s->sob_m = m;
         dev.sob_scale = scale;
-        std::vector<uint32_t> X(size_t(1024) * scale), Y(size_t(1024) * scale);
+        std::vector<uint32_t> X(size_t(1024) * scale, 0u), Y(size_t(1024) * scale, 0u);
         for (int dim = 0; dim < 1024; ++dim) {
             uint32_t col[64];
             for (uint32_t c = 0; c < 2 * m; ++c) col[c] = sobol_word(kVdCSobolMatricesInv[m - 1][c], dim);
-            uint32_t* x = &X[size_t(dim) * scale];
-            uint32_t* y = &Y[size_t(dim) * scale];
-            x[0] = y[0] = 0;
             for (uint32_t p = 1; p < scale; ++p) {
                 const int low = __builtin_ctz(p);
-                y[p] = y[p & (p - 1)] ^ col[low];      // pixel y occupies bits 0..m-1 of the interval number
-                x[p] = x[p & (p - 1)] ^ col[m + low];  // pixel x occupies bits m..2m-1
+                const uint32_t prev = p & (p - 1);
+                Y[size_t(p) * 1024 + dim] = Y[size_t(prev) * 1024 + dim] ^ col[low];      // pixel y: bits 0..m-1 of the interval number
+                X[size_t(p) * 1024 + dim] = X[size_t(prev) * 1024 + dim] ^ col[m + low];  // pixel x: bits m..2m-1
             }
         }
         if (int rc = upload(s, X.data(), X.size(), &dev.sob_x)) return rc;
@@ -325,25 +359,36 @@ void ws_release(Workspace& ws) {
 }
 
 int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
-    if (n_slots > ws.cap_slots || n_frames > ws.frame_cap) {
+    const uint32_t n_shards = (n_slots + kShard - 1) / kShard;
+    const uint32_t padded = n_shards * kShard;
+    if (padded > ws.cap_slots || n_frames > ws.frame_cap) {
         ws_release(ws);
+        ws.n_shards = n_shards;
         for (int k = 0; k < 2; ++k) {
-            if (int rc = ws_alloc(ws, &ws.q[k].a, n_slots)) return rc;
-            if (int rc = ws_alloc(ws, &ws.q[k].b, n_slots)) return rc;
-            if (int rc = ws_alloc(ws, &ws.q[k].c, n_slots)) return rc;
-            if (int rc = ws_alloc(ws, &ws.q[k].slot, n_slots)) return rc;
-            if (int rc = ws_alloc(ws, &ws.q[k].hit, n_slots)) return rc;
+            if (int rc = ws_alloc(ws, &ws.q[k].a, padded)) return rc;
+            if (int rc = ws_alloc(ws, &ws.q[k].b, padded)) return rc;
+            if (int rc = ws_alloc(ws, &ws.q[k].c, padded)) return rc;
+            if (int rc = ws_alloc(ws, &ws.q[k].slot, padded)) return rc;
         }
-        if (int rc = ws_alloc(ws, &ws.sh.a, n_slots)) return rc;
-        if (int rc = ws_alloc(ws, &ws.sh.b, n_slots)) return rc;
-        if (int rc = ws_alloc(ws, &ws.sh.c, n_slots)) return rc;
-        if (int rc = ws_alloc(ws, &ws.lbuf, n_slots)) return rc;
-        if (int rc = ws_alloc(ws, &ws.counters, kCounterWords)) return rc;
+        if (int rc = ws_alloc(ws, &ws.hq.h0, padded)) return rc;
+        if (int rc = ws_alloc(ws, &ws.hq.h1, padded)) return rc;
+        if (int rc = ws_alloc(ws, &ws.sh.a, padded)) return rc;
+        if (int rc = ws_alloc(ws, &ws.sh.b, padded)) return rc;
+        if (int rc = ws_alloc(ws, &ws.sh.c, padded)) return rc;
+        if (int rc = ws_alloc(ws, &ws.lbuf, padded)) return rc;
+        if (int rc = ws_alloc(ws, &ws.counters, ws.counter_words())) return rc;
         if (int rc = ws_alloc(ws, &ws.frame_tab, n_frames * 1024)) return rc;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ws.h_counters), kCounterWords * sizeof(uint32_t), hipHostMallocDefault));
-        ws.cap_slots = n_slots;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ws.h_counters), ws.counter_words() * sizeof(uint32_t), hipHostMallocDefault));
+        ws.cap_slots = padded;
         ws.frame_cap = n_frames;
     }
+    // a smaller request reuses the buffers with fewer shards in play; counters are laid out for this request
+    ws.n_shards = n_shards;
+    ws.q[0].count = ws.counters;
+    ws.q[1].count = ws.counters + n_shards;
+    ws.sh.count = ws.counters + 2 * size_t(n_shards);
+    ws.hq.count = ws.counters + 3 * size_t(n_shards);
+    ws.misc = ws.counters + 4 * size_t(n_shards);
     return PT_OK;
 }
 
@@ -392,50 +437,84 @@ struct Timer {
 
 inline uint32_t blocks(uint32_t n, uint32_t b) { return (n + b - 1) / b; }
 
-// The bounce loop shared by pt_hip_render_device and pt_hip_li.  Queue 0 of the workspace holds the paths that
-// k_generate left alive; counters were read back into h_counters[0].
+struct Fill {
+    uint32_t max = 0;
+    uint64_t sum = 0;
+};
+inline Fill fill_of(const uint32_t* counts, uint32_t n) {
+    Fill f;
+    for (uint32_t i = 0; i < n; ++i) {
+        f.max = std::max(f.max, counts[i]);
+        f.sum += counts[i];
+    }
+    return f;
+}
+
+int launch_generate(pt_hip_scene* s, const PassArgs& pa, Timer& tm, bool count) {
+    Workspace& ws = s->ws;
+    HIP_TRY(hipMemsetAsync(ws.counters, 0, ws.counter_words() * sizeof(uint32_t), g_stream));
+    if (int rc = tm.begin(PT_K_GENERATE)) return rc;
+    if (count)
+        hipLaunchKernelGGL(k_generate<Count>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.hq, ws.lbuf,
+                           ws.misc);
+    else
+        hipLaunchKernelGGL(k_generate<NoCount>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.hq,
+                           ws.lbuf, ws.misc);
+    if (int rc = tm.end()) return rc;
+    // every path that k_generate kept is also a hit-list entry at the same position
+    HIP_TRY(hipMemcpyAsync(ws.hq.count, ws.q[0].count, ws.n_shards * sizeof(uint32_t), hipMemcpyDeviceToDevice, g_stream));
+    return PT_OK;
+}
+
+// The bounce loop shared by pt_hip_render_device and pt_hip_li; k_generate has filled path queue 0 and the hit list.
 int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bool count) {
     Workspace& ws = s->ws;
-    const Counters cnt{ws.counters};
-    uint32_t n_active = ws.h_counters[0];
+    const uint32_t K = ws.n_shards;
+    HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, ws.counter_words() * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    Fill hits = fill_of(ws.h_counters + 3 * size_t(K), K);
     int cur = 0;
     // every loop iteration is one bounce; specular chains do not advance the bounce counter (src/integrator.cpp:84-87),
     // so bound the loop independently
-    for (uint32_t iter = 0; n_active > 0 && iter < 8 * pa.max_bounce; ++iter) {
-        HIP_TRY(hipMemsetAsync(ws.counters, 0, 2 * sizeof(uint32_t), g_stream));
+    for (uint32_t iter = 0; hits.max > 0 && iter < 8 * pa.max_bounce; ++iter) {
+        const int nxt = cur ^ 1;
+        HIP_TRY(hipMemsetAsync(ws.q[nxt].count, 0, K * sizeof(uint32_t), g_stream));
+        HIP_TRY(hipMemsetAsync(ws.sh.count, 0, K * sizeof(uint32_t), g_stream));
         if (int rc = tm.begin(PT_K_SHADE)) return rc;
-        hipLaunchKernelGGL(k_shade, dim3(blocks(n_active, 256)), dim3(256), 0, g_stream, s->dev, pa, ws.q[cur], n_active, ws.q[cur ^ 1],
-                           ws.sh, ws.lbuf, cnt);
+        hipLaunchKernelGGL(k_shade, dim3(blocks(hits.max, 256), K), dim3(256), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.q[nxt], ws.sh,
+                           ws.lbuf);
         if (int rc = tm.end()) return rc;
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemsetAsync(ws.hq.count, 0, K * sizeof(uint32_t), g_stream));
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 3 * size_t(K) * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
-        const uint32_t n_next = ws.h_counters[0], n_shadow = ws.h_counters[1];
-        if (n_shadow) {
+        const Fill next = fill_of(ws.h_counters + size_t(nxt) * K, K), shadow = fill_of(ws.h_counters + 2 * size_t(K), K);
+        if (shadow.max) {
             if (int rc = tm.begin(PT_K_SHADOW)) return rc;
             if (count)
-                hipLaunchKernelGGL(k_shadow<Count>, dim3(blocks(n_shadow, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.sh, n_shadow,
-                                   pa.traversal, ws.lbuf, cnt);
+                hipLaunchKernelGGL(k_shadow<Count>, dim3(blocks(shadow.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.sh, pa.traversal,
+                                   ws.lbuf, ws.misc);
             else
-                hipLaunchKernelGGL(k_shadow<NoCount>, dim3(blocks(n_shadow, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.sh, n_shadow,
-                                   pa.traversal, ws.lbuf, cnt);
+                hipLaunchKernelGGL(k_shadow<NoCount>, dim3(blocks(shadow.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.sh,
+                                   pa.traversal, ws.lbuf, ws.misc);
             if (int rc = tm.end()) return rc;
         }
-        if (n_next) {
+        if (next.max) {
             if (int rc = tm.begin(PT_K_EXTEND)) return rc;
             if (count)
-                hipLaunchKernelGGL(k_extend<Count>, dim3(blocks(n_next, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.q[cur ^ 1], n_next,
-                                   pa.traversal, cnt);
+                hipLaunchKernelGGL(k_extend<Count>, dim3(blocks(next.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], ws.hq,
+                                   pa.traversal, ws.misc);
             else
-                hipLaunchKernelGGL(k_extend<NoCount>, dim3(blocks(n_next, kBlock)), dim3(kBlock), 0, g_stream, s->dev, ws.q[cur ^ 1], n_next,
-                                   pa.traversal, cnt);
+                hipLaunchKernelGGL(k_extend<NoCount>, dim3(blocks(next.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], ws.hq,
+                                   pa.traversal, ws.misc);
             if (int rc = tm.end()) return rc;
         }
         if (st) {
-            st->any_rays += n_shadow;
-            st->closest_rays += n_next;
+            st->any_rays += shadow.sum;
+            st->closest_rays += next.sum;
         }
-        n_active = n_next;
-        cur ^= 1;
+        // the next hit list is a subset of the next path queue, shard by shard: its largest fill bounds the shade grid
+        hits = next;
+        cur = nxt;
     }
     HIP_TRY(hipGetLastError());
     return PT_OK;
@@ -653,17 +732,7 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         pa.integrator = p.integrator;
         pa.traversal = p.traversal;
         pa.max_bounce = p.max_bounce;
-        HIP_TRY(hipMemsetAsync(ws.counters, 0, kCounterWords * sizeof(uint32_t), g_stream));
-        if (int rc = tm.begin(PT_K_GENERATE)) return rc;
-        if (count)
-            hipLaunchKernelGGL(k_generate<Count>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.lbuf,
-                               Counters{ws.counters});
-        else
-            hipLaunchKernelGGL(k_generate<NoCount>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0],
-                               ws.lbuf, Counters{ws.counters});
-        if (int rc = tm.end()) return rc;
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipStreamSynchronize(g_stream));
+        if (int rc = launch_generate(s, pa, tm, count)) return rc;
         if (st) {
             st->paths += uint64_t(W) * H * nf;
             st->closest_rays += uint64_t(W) * H * nf;
@@ -672,11 +741,11 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         if (int rc = tm.begin(PT_K_FILM)) return rc;
         hipLaunchKernelGGL(k_film, dim3(((tiles_x + 1) / 2) * ((tiles_y + 1) / 2)), dim3(256), 0, g_stream, s->dev, pa, ws.lbuf, d_film);
         if (int rc = tm.end()) return rc;
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.misc, kMiscWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
         HIP_TRY(hipGetLastError());
         if (st) {
-            st->exact_retraces += ws.h_counters[2];
+            st->exact_retraces += ws.h_counters[0];
             for (int k = 0; k < 3; ++k) {
                 st->nodes_fetched[k] += uint64_t(ws.h_counters[4 + 4 * k]) | (uint64_t(ws.h_counters[5 + 4 * k]) << 32);
                 st->tris_fetched[k] += uint64_t(ws.h_counters[6 + 4 * k]) | (uint64_t(ws.h_counters[7 + 4 * k]) << 32);
@@ -758,17 +827,7 @@ int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pi
         pa.list_pixel_sample = d_ps;
         Timer tm{s, true};
         const bool count = (p.flags & PT_FLAG_COUNT_WORK) != 0;
-        HIP_TRY(hipMemsetAsync(ws.counters, 0, kCounterWords * sizeof(uint32_t), g_stream));
-        if (int r = tm.begin(PT_K_GENERATE)) return r;
-        if (count)
-            hipLaunchKernelGGL(k_generate<Count>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.lbuf,
-                               Counters{ws.counters});
-        else
-            hipLaunchKernelGGL(k_generate<NoCount>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0],
-                               ws.lbuf, Counters{ws.counters});
-        if (int r = tm.end()) return r;
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, kCounterWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipStreamSynchronize(g_stream));
+        if (int r = launch_generate(s, pa, tm, count)) return r;
         if (st) {
             st->paths += n;
             st->closest_rays += n;

@@ -10,18 +10,21 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLeafCountShift = 27;
 constexpr uint32_t kLeafFirstMask = (1u << kLeafCountShift) - 1u;
 
-struct DevMaterial {
-    float kd[3];
-    float ks[3];
-    float ns;
-    int32_t tex;
-};
+// Shading record of one triangle: exactly one 128-byte line, 8 x float4, everything the shade step needs about the
+// surface it hit (the reference chases Triangle* -> TriangleMesh -> index arrays -> vertex arrays, and Material*,
+// AreaLight*: include/pt/shape.h:58-63, include/pt/mesh.h:31-55):
+//   r0 {v0.x v0.y v0.z v1.x}  r1 {v1.y v1.z v2.x v2.y}  r2 {v2.z n0.x n0.y n0.z}  r3 {n1.x n1.y n1.z n2.x}
+//   r4 {n2.y n2.z bits(flags) bits(light_id)}  r5 {kd.r kd.g kd.b ns}  r6 {ks.r ks.g ks.b bits(tex)}
+//   r7 {lemit.r lemit.g lemit.b inv_area}   (zero when the triangle is not an emitter)
+constexpr uint32_t kTriHasNormals = 1u;  // mesh has normals and this face's first normal index is non-zero (mesh.h:37-39)
+constexpr uint32_t kTriHasUvs = 2u;      // same for texture coordinates (mesh.h:46-48)
+constexpr int kTriRecVec4 = 8;
 
-struct DevLight {
-    uint32_t tri;
-    float lemit[3];
-    float inv_area;  // float(1.0 / double(area)): include/pt/shape.h:37, src/shape.cpp:111
-};
+// Sampling record of one area light, 6 x float4 (AreaLight + its Triangle, src/light.cpp:10-33, src/shape.cpp:95-113):
+//   l0 {v0.x v0.y v0.z v1.x}  l1 {v1.y v1.z v2.x v2.y}  l2 {v2.z n0.x n0.y n0.z}  l3 {n1.x n1.y n1.z n2.x}
+//   l4 {n2.y n2.z bits(flags) inv_area}  l5 {lemit.r lemit.g lemit.b 0}
+// inv_area = float(1.0 / double(area)) (include/pt/shape.h:37, src/shape.cpp:111).
+constexpr int kLightRecVec4 = 6;
 
 struct DevTexture {
     uint32_t w, h;
@@ -46,24 +49,20 @@ struct DevScene {
     uint32_t wide_root;  // reference of the root (an interior index, or a leaf reference for tiny scenes)
     // ---- triangles in leaf order, 3 x float4 each: {p0.xyz, bits(prim)} {e1.xyz, 0} {e2.xyz, 0}
     const float4* tris;
-    // ---- shading data (original triangle order)
-    const float* verts;
-    const float* normals;
+    // ---- shading records (original triangle order) and light records (reference light order)
+    const float4* trec;
+    const float4* lrec;
+    // ---- only for textured materials
     const float* uvs;
-    const uint32_t* vi;
-    const uint32_t* ni;
     const uint32_t* ti;
-    const uint32_t* mat_id;
-    const int32_t* light_id;
-    const DevMaterial* mats;
-    const DevLight* lights;
     const DevTexture* textures;
     const float* tex_data;
-    uint32_t n_tris, n_normals, n_uvs, n_lights;
+    uint32_t n_tris, n_lights;
     DevCamera cam;
-    // ---- Sobol' sampler: value(dim) = F[frame][dim] ^ X[dim][px] ^ Y[dim][py]  (all XOR-linear in the index bits)
-    const uint32_t* sob_x;  // 1024 x scale
-    const uint32_t* sob_y;  // 1024 x scale
+    // ---- Sobol' sampler: word(dim) = F[frame][dim] ^ X[px][dim] ^ Y[py][dim]  (all XOR-linear in the index bits);
+    //      rows of 1024 words, so the consecutive dimensions of one bounce sit in one cache line per table
+    const uint32_t* sob_x;  // scale x 1024
+    const uint32_t* sob_y;  // scale x 1024
     uint32_t sob_scale;     // roundUpPow2(max(W,H)) (src/sampler.cpp:92)
     float filter[33];       // tabulated Gaussian (src/block.cpp:14-25)
 };

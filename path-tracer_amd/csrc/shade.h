@@ -8,61 +8,81 @@
 
 namespace ptd {
 
-// ---------------------------------------------------------------------------------------------------- mesh access
+// ---------------------------------------------------------------------------------------------------- records
 
-PTD V3 ld3(const float* p, uint32_t i) { return V3{p[3 * size_t(i)], p[3 * size_t(i) + 1], p[3 * size_t(i) + 2]}; }
+// One triangle's shading record, loaded as 8 independent 16-byte reads of one 128-byte line.
+struct TriRec {
+    float4 r[kTriRecVec4];
+    PTD void load(const DevScene& sc, uint32_t prim) {
+        const float4* p = sc.trec + size_t(prim) * kTriRecVec4;
+#pragma unroll
+        for (int k = 0; k < kTriRecVec4; ++k) r[k] = p[k];
+    }
+    PTD V3 v0() const { return V3{r[0].x, r[0].y, r[0].z}; }
+    PTD V3 v1() const { return V3{r[0].w, r[1].x, r[1].y}; }
+    PTD V3 v2() const { return V3{r[1].z, r[1].w, r[2].x}; }
+    PTD V3 n0() const { return V3{r[2].y, r[2].z, r[2].w}; }
+    PTD V3 n1() const { return V3{r[3].x, r[3].y, r[3].z}; }
+    PTD V3 n2() const { return V3{r[3].w, r[4].x, r[4].y}; }
+    PTD uint32_t flags() const { return as_u(r[4].z); }
+    PTD int32_t light_id() const { return int32_t(as_u(r[4].w)); }
+    PTD V3 kd() const { return V3{r[5].x, r[5].y, r[5].z}; }
+    PTD float ns() const { return r[5].w; }
+    PTD V3 ks() const { return V3{r[6].x, r[6].y, r[6].z}; }
+    PTD int32_t tex() const { return int32_t(as_u(r[6].w)); }
+    PTD V3 lemit() const { return V3{r[7].x, r[7].y, r[7].z}; }
+    PTD float inv_area() const { return r[7].w; }
+};
 
-PTD void tri_verts(const DevScene& sc, uint32_t f, V3& a, V3& b, V3& c) {  // include/pt/mesh.h:31-35
-    a = ld3(sc.verts, sc.vi[3 * size_t(f) + 0] - 1u);
-    b = ld3(sc.verts, sc.vi[3 * size_t(f) + 1] - 1u);
-    c = ld3(sc.verts, sc.vi[3 * size_t(f) + 2] - 1u);
-}
-PTD bool tri_normals(const DevScene& sc, uint32_t f, V3& a, V3& b, V3& c) {  // include/pt/mesh.h:37-44
-    if (sc.n_normals == 0u) return false;
-    const uint32_t i0 = sc.ni[3 * size_t(f)];
-    if (i0 == 0u) return false;
-    a = ld3(sc.normals, i0 - 1u);
-    b = ld3(sc.normals, sc.ni[3 * size_t(f) + 1] - 1u);
-    c = ld3(sc.normals, sc.ni[3 * size_t(f) + 2] - 1u);
-    return true;
-}
-PTD bool tri_uvs(const DevScene& sc, uint32_t f, V2& a, V2& b, V2& c) {  // include/pt/mesh.h:46-53
-    if (sc.n_uvs == 0u) return false;
-    const uint32_t i0 = sc.ti[3 * size_t(f)];
-    if (i0 == 0u) return false;
-    const uint32_t i1 = sc.ti[3 * size_t(f) + 1], i2 = sc.ti[3 * size_t(f) + 2];
-    a = V2{sc.uvs[2 * size_t(i0 - 1u)], sc.uvs[2 * size_t(i0 - 1u) + 1]};
-    b = V2{sc.uvs[2 * size_t(i1 - 1u)], sc.uvs[2 * size_t(i1 - 1u) + 1]};
-    c = V2{sc.uvs[2 * size_t(i2 - 1u)], sc.uvs[2 * size_t(i2 - 1u) + 1]};
-    return true;
-}
+struct LightRec {
+    float4 l[kLightRecVec4];
+    PTD void load(const DevScene& sc, uint32_t li) {
+        const float4* p = sc.lrec + size_t(li) * kLightRecVec4;
+#pragma unroll
+        for (int k = 0; k < kLightRecVec4; ++k) l[k] = p[k];
+    }
+    PTD V3 v0() const { return V3{l[0].x, l[0].y, l[0].z}; }
+    PTD V3 v1() const { return V3{l[0].w, l[1].x, l[1].y}; }
+    PTD V3 v2() const { return V3{l[1].z, l[1].w, l[2].x}; }
+    PTD V3 n0() const { return V3{l[2].y, l[2].z, l[2].w}; }
+    PTD V3 n1() const { return V3{l[3].x, l[3].y, l[3].z}; }
+    PTD V3 n2() const { return V3{l[3].w, l[4].x, l[4].y}; }
+    PTD uint32_t flags() const { return as_u(l[4].z); }
+    PTD float inv_area() const { return l[4].w; }
+    PTD V3 lemit() const { return V3{l[5].x, l[5].y, l[5].z}; }
+};
 
 // ---------------------------------------------------------------------------------------------------- surface point
 
 struct Surf {
     V3 p, n, ng;
-    V2 uv;
     Frame ts;
-    uint32_t prim;
 };
 
-// Intersection::complete (src/shape.cpp:145-166); bary = (1 - u - v, u, v) (src/shape.cpp:86)
-PTD void complete(const DevScene& sc, uint32_t prim, float u, float v, Surf& o) {
+// Intersection::complete (src/shape.cpp:145-166) without the uv part; bary = (1 - u - v, u, v) (src/shape.cpp:86)
+PTD void complete(const TriRec& t, float u, float v, Surf& o) {
     const float b0 = 1 - u - v, b1 = u, b2 = v;
-    V3 v0, v1, v2;
-    tri_verts(sc, prim, v0, v1, v2);
-    o.prim = prim;
+    const V3 v0 = t.v0(), v1 = t.v1(), v2 = t.v2();
     o.p = v0 * b0 + v1 * b1 + v2 * b2;
     const V3 g = cross(v0 - v2, v1 - v2);
-    V3 n = g, n0, n1, n2;
-    if (tri_normals(sc, prim, n0, n1, n2)) n = n0 * b0 + n1 * b1 + n2 * b2;
+    V3 n = g;
+    if (t.flags() & kTriHasNormals) n = t.n0() * b0 + t.n1() * b1 + t.n2() * b2;
     o.n = normalized(n);
     o.ng = normalized(g);
     o.ts = Frame(o.n);
+}
+
+// uv of Intersection::complete (src/shape.cpp:163-165): only textured materials ever read it
+PTD V2 surface_uv(const DevScene& sc, uint32_t prim, uint32_t flags, float u, float v) {
+    const float b0 = 1 - u - v, b1 = u, b2 = v;
     V2 a{0.0f, 0.0f}, b{1.0f, 0.0f}, c{1.0f, 1.0f};
-    tri_uvs(sc, prim, a, b, c);
-    o.uv.x = a.x * b0 + b.x * b1 + c.x * b2;
-    o.uv.y = a.y * b0 + b.y * b1 + c.y * b2;
+    if (flags & kTriHasUvs) {
+        const uint32_t i0 = sc.ti[3 * size_t(prim)] - 1u, i1 = sc.ti[3 * size_t(prim) + 1] - 1u, i2 = sc.ti[3 * size_t(prim) + 2] - 1u;
+        a = V2{sc.uvs[2 * size_t(i0)], sc.uvs[2 * size_t(i0) + 1]};
+        b = V2{sc.uvs[2 * size_t(i1)], sc.uvs[2 * size_t(i1) + 1]};
+        c = V2{sc.uvs[2 * size_t(i2)], sc.uvs[2 * size_t(i2) + 1]};
+    }
+    return V2{a.x * b0 + b.x * b1 + c.x * b2, a.y * b0 + b.y * b1 + c.y * b2};
 }
 
 // ---------------------------------------------------------------------------------------------------- texture
@@ -94,17 +114,14 @@ PTD V3 tex_sample(const DevScene& sc, const DevTexture& t, V2 uv) {  // src/bitm
 struct Mat {
     V3 kd, ks;
     float ns;
-    int32_t tex;
 };
-PTD Mat load_mat(const DevScene& sc, uint32_t prim) {
-    const DevMaterial& m = sc.mats[sc.mat_id[prim]];
-    return Mat{V3{m.kd[0], m.kd[1], m.kd[2]}, V3{m.ks[0], m.ks[1], m.ks[2]}, m.ns, m.tex};
+// Material::getBaseColor(uv) (src/material.cpp:9-16) folded into the material the shade step works with
+PTD Mat surface_material(const DevScene& sc, const TriRec& t, uint32_t prim, float u, float v) {
+    Mat m{t.kd(), t.ks(), t.ns()};
+    if (t.tex() >= 0) m.kd = tex_sample(sc, sc.textures[t.tex()], surface_uv(sc, prim, t.flags(), u, v));
+    return m;
 }
 PTD bool is_mirror(const Mat& m) { return m.ks.x > 999.0f || m.ks.y > 999.0f || m.ks.z > 999.0f; }
-PTD V3 base_color(const DevScene& sc, const Mat& m, V2 uv) {  // src/material.cpp:9-16
-    if (m.tex >= 0) return tex_sample(sc, sc.textures[m.tex], uv);
-    return m.kd;
-}
 // mix() on floats (include/pt/common.h:82-85): a * (1.0 - f) is a double product, b * f a float product
 PTD float mixf(float a, float b, float f) { return float(double(a) * (1.0 - double(f)) + double(b * f)); }
 PTD V3 reflect(V3 w, V3 n) { return -w + (2.0f * dot(w, n)) * n; }  // include/pt/common.h:87-89
@@ -120,30 +137,29 @@ PTD V3 phong_lobe(V2 u, float sh) {  // include/pt/common.h:107-112
     return V3{st * cosf(phi), st * sinf(phi), ct};
 }
 
-// Material::BRDF (src/material.cpp:18-38); `kd` is the base colour already looked up at the hit
-PTD V3 brdf_eval(const Mat& m, V3 kd, V3 n, V3 wo, V3 wi) {
-    if (is_mirror(m)) return mk3(0.0f);
-    const V3 diffuse = kd * kInvPi;
+// Material::BRDF (src/material.cpp:18-38) and Material::pdf (src/material.cpp:92-115) for the same pair of directions
+// (sampleLd evaluates both, src/integrator.cpp:131-137); the Phong power is shared.
+PTD void brdf_eval_pdf(const Mat& m, V3 n, V3 wo, V3 wi, V3& f, float& pdf) {
+    if (is_mirror(m)) {
+        f = mk3(0.0f);
+        pdf = 0.0f;
+        return;
+    }
     const V3 r = reflect(wo, n);
     const float cosRV = std_max(dot(wi, r), 0.0f);
+    const float powRV = powf(cosRV, m.ns);
     const float normalization = (m.ns + 2.0f) * kInvTwoPi;
-    const V3 spec = m.ks * normalization * powf(cosRV, m.ns);
-    return diffuse + spec;
-}
-
-// Material::pdf (src/material.cpp:92-115)
-PTD float brdf_pdf(const Mat& m, V3 kd, V3 n, V3 wo, V3 wi) {
-    if (is_mirror(m)) return 0.0f;
-    const float sumKd = sum3(kd), sumKs = sum3(m.ks);
+    f = m.kd * kInvPi + m.ks * normalization * powRV;
+    const float sumKd = sum3(m.kd), sumKs = sum3(m.ks);
     const float sumKdKs = sumKd + sumKs;
-    if (sumKdKs == 0.0f) return 0.0f;
+    if (sumKdKs == 0.0f) {
+        pdf = 0.0f;
+        return;
+    }
     const float specProb = sumKs / sumKdKs;
-    const V3 r = reflect(wo, n);
-    const float cosRV = std_max(dot(wi, r), 0.0f);
-    const float pdf_spec = (m.ns + 1.0f) * kInvTwoPi * powf(cosRV, m.ns);
-    const float cosTheta = fabsf(dot(wi, n));
-    const float pdf_diff = cosTheta * kInvPi;
-    return mixf(pdf_diff, pdf_spec, specProb);
+    const float pdf_spec = (m.ns + 1.0f) * kInvTwoPi * powRV;
+    const float pdf_diff = fabsf(dot(wi, n)) * kInvPi;
+    pdf = mixf(pdf_diff, pdf_spec, specProb);
 }
 
 struct BSample {
@@ -153,7 +169,7 @@ struct BSample {
 };
 
 // Material::sampleBRDF (src/material.cpp:40-90)
-PTD BSample brdf_sample(const Mat& m, V3 kd, const Surf& it, V3 wo, float uc, V2 u) {
+PTD BSample brdf_sample(const Mat& m, const Surf& it, V3 wo, float uc, V2 u) {
     BSample out{mk3(0.0f), mk3(0.0f), 0.0f, false};
     if (is_mirror(m)) {
         out.wi = reflect(wo, it.n);
@@ -161,7 +177,7 @@ PTD BSample brdf_sample(const Mat& m, V3 kd, const Surf& it, V3 wo, float uc, V2
         out.specular = true;
         return out;
     }
-    const float sumKd = sum3(kd), sumKs = sum3(m.ks);
+    const float sumKd = sum3(m.kd), sumKs = sum3(m.ks);
     const float sumKdKs = sumKd + sumKs;
     if (sumKdKs == 0.0f) return out;
     const float specProb = sumKs / sumKdKs;
@@ -180,7 +196,7 @@ PTD BSample brdf_sample(const Mat& m, V3 kd, const Surf& it, V3 wo, float uc, V2
     const float powRV = powf(cosRV, m.ns);
     const float pdf_spec = (m.ns + 1.0f) * kInvTwoPi * powRV;
     const float pdf_diff = cosTheta * kInvPi;
-    out.f = kd * kInvPi + m.ks * (m.ns + 2.0f) * kInvTwoPi * powRV;
+    out.f = m.kd * kInvPi + m.ks * (m.ns + 2.0f) * kInvTwoPi * powRV;
     out.pdf = mixf(pdf_diff, pdf_spec, specProb);
     out.wi = wi;
     return out;
@@ -194,17 +210,16 @@ struct LiSample {
 };
 
 // AreaLight::sampleLi (src/light.cpp:18-33) with Triangle::sample (src/shape.cpp:95-113)
-PTD LiSample light_sample(const DevScene& sc, const DevLight& l, V3 sp, V3 sn, V2 u) {
+PTD LiSample light_sample(const LightRec& l, V3 sp, V3 sn, V2 u) {
     LiSample o{mk3(0.0f), mk3(0.0f), mk3(0.0f), mk3(0.0f), 0.0f};
     const float su0 = sqrtf(u.x);
     const float b0 = 1 - su0, b1 = u.y * su0;
     const float b2 = 1 - b0 - b1;
-    V3 v0, v1, v2, n0, n1, n2;
-    tri_verts(sc, l.tri, v0, v1, v2);
+    const V3 v0 = l.v0(), v1 = l.v1(), v2 = l.v2();
     const V3 lp = v0 * b0 + v1 * b1 + v2 * b2;
     V3 ln;
-    if (tri_normals(sc, l.tri, n0, n1, n2))
-        ln = n0 * b0 + n1 * b1 + n2 * b2;
+    if (l.flags() & kTriHasNormals)
+        ln = l.n0() * b0 + l.n1() * b1 + l.n2() * b2;
     else
         ln = cross(v0 - v2, v1 - v2);
     ln = normalized(ln);
@@ -214,20 +229,20 @@ PTD LiSample light_sample(const DevScene& sc, const DevLight& l, V3 sp, V3 sn, V
     const float cos_lw = dot(ln, -wi);
     const float cos_sw = dot(sn, wi);
     if (cos_lw > 0.0f && cos_sw > 0.0f && dist > 0.0f) {
-        o.L = V3{l.lemit[0], l.lemit[1], l.lemit[2]};
+        o.L = l.lemit();
         o.wi = wi;
         o.p = lp;
         o.n = ln;
-        o.pdfDir = l.inv_area * dist * dist / cos_lw;
+        o.pdfDir = l.inv_area() * dist * dist / cos_lw;
     }
     return o;
 }
 
 // AreaLight::pdfLi (src/light.cpp:46-50)
-PTD float light_pdf(const DevLight& l, V3 lp, V3 ln, V3 ray_o, V3 ray_d) {
+PTD float light_pdf(float inv_area, V3 lp, V3 ln, V3 ray_o, V3 ray_d) {
     const float dist = norm(lp - ray_o);
     const float cos_lw = dot(ln, -ray_d);
-    return l.inv_area * dist * dist / cos_lw;
+    return inv_area * dist * dist / cos_lw;
 }
 
 PTD float power_heuristic(float f, float g) {  // src/integrator.cpp:15-18
@@ -262,43 +277,73 @@ PTD void camera_ray(const DevCamera& c, V2 sp, V3& o, V3& d, float& tmin, float&
 
 // SobolSampler (src/sampler.cpp:96-123).  The 32-bit Sobol' word of a dimension is XOR-linear in the bits of the
 // sample index, and the index is XOR-linear in (sample number, pixel x, pixel y) (sobolIntervalToIndex,
-// src/sampler.cpp:16-36), so the word splits into three table look-ups.  frame_tab points at this sample number's row
-// of 1024 words.
+// src/sampler.cpp:16-36), so the word splits into three table look-ups:
+//     word(dim) = F[sample number][dim] ^ X[px][dim] ^ Y[py][dim]
+// Every table row holds the 1024 dimensions contiguously.  A bounce consumes up to 7 consecutive dimensions, so the
+// sampler prefetches a window of 8 words per table (two 16-byte reads each) when it is started.
+struct __attribute__((packed, aligned(4))) Words4 {
+    uint32_t w[4];
+};
+
+PTD float sobol_to_float(uint32_t v) { return std_min(float(v) * 0x1p-32f, kOneMinusEps); }  // src/sampler.cpp:13
+
 struct Sampler {
-    const uint32_t* frame_tab;
-    const uint32_t* sx;
-    const uint32_t* sy;
-    uint32_t scale, px, py;
+    const uint32_t* fr;  // F row of this sample number
+    const uint32_t* xr;  // X row of this pixel column
+    const uint32_t* yr;  // Y row of this pixel row
+    uint32_t win[8];     // words of dimensions [base, base + 8)
+    int base;
     int dim;
-    PTD void start(const DevScene& sc, const uint32_t* frame_row, uint32_t x, uint32_t y, int first_dim) {
-        frame_tab = frame_row;
-        sx = sc.sob_x;
-        sy = sc.sob_y;
-        scale = sc.sob_scale;
-        px = x;
-        py = y;
+    PTD void start(const DevScene& sc, const uint32_t* frame_row, uint32_t px, uint32_t py, int first_dim) {
+        fr = frame_row;
+        xr = sc.sob_x + size_t(px) * 1024u;
+        yr = sc.sob_y + size_t(py) * 1024u;
         dim = first_dim;
+        base = -1;
+        if (first_dim + 8 <= 1024) {
+            base = first_dim;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const Words4 a = *reinterpret_cast<const Words4*>(fr + first_dim + 4 * h);
+                const Words4 b = *reinterpret_cast<const Words4*>(xr + first_dim + 4 * h);
+                const Words4 c = *reinterpret_cast<const Words4*>(yr + first_dim + 4 * h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) win[4 * h + k] = a.w[k] ^ b.w[k] ^ c.w[k];
+            }
+        }
     }
-    PTD float value(int d) const {  // sobolSample, src/sampler.cpp:6-14
-        const uint32_t v = frame_tab[d] ^ sx[size_t(d) * scale + px] ^ sy[size_t(d) * scale + py];
-        return std_min(float(v) * 0x1p-32f, kOneMinusEps);
+    PTD uint32_t word(int d) const {
+        const int k = d - base;
+        if (base >= 0 && k >= 0 && k < 8) {
+            uint32_t v = win[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) v = (k == j) ? win[j] : v;
+            return v;
+        }
+        return fr[d] ^ xr[d] ^ yr[d];
     }
-    PTD float s1() {
+    PTD float value(int d) const { return sobol_to_float(word(d)); }
+    PTD float s1() {  // src/sampler.cpp:102-106
         if (dim >= 1024) dim = 2;
         return value(dim++);
     }
-    PTD V2 s2() {
+    PTD V2 s2() {  // src/sampler.cpp:108-114
         if (dim + 1 >= 1024) dim = 2;
         const V2 u{value(dim), value(dim + 1)};
         dim += 2;
         return u;
     }
-    PTD V2 pixel2() const {  // samplePixel2D, src/sampler.cpp:116-123
-        V2 u{value(0), value(1)};
-        u.x = std_clamp(u.x * float(int(scale)) - float(int(px)), 0.0f, kOneMinusEps);
-        u.y = std_clamp(u.y * float(int(scale)) - float(int(py)), 0.0f, kOneMinusEps);
-        return u;
-    }
 };
+
+// samplePixel2D (src/sampler.cpp:116-123): dimensions 0 and 1, remapped to the pixel
+PTD V2 pixel_jitter(const DevScene& sc, const uint32_t* frame_row, uint32_t px, uint32_t py) {
+    const uint2 f = *reinterpret_cast<const uint2*>(frame_row);
+    const uint2 x = *reinterpret_cast<const uint2*>(sc.sob_x + size_t(px) * 1024u);
+    const uint2 y = *reinterpret_cast<const uint2*>(sc.sob_y + size_t(py) * 1024u);
+    V2 u{sobol_to_float(f.x ^ x.x ^ y.x), sobol_to_float(f.y ^ x.y ^ y.y)};
+    u.x = std_clamp(u.x * float(int(sc.sob_scale)) - float(int(px)), 0.0f, kOneMinusEps);
+    u.y = std_clamp(u.y * float(int(sc.sob_scale)) - float(int(py)), 0.0f, kOneMinusEps);
+    return u;
+}
 
 }  // namespace ptd
