@@ -203,6 +203,11 @@ int pt_hip_li(pt_hip_scene* scene, const pt_render_params* params, const int32_t
 int pt_hip_sobol(pt_hip_scene* scene, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim, size_t n,
                  float* out);
 
+/* No counterpart in the reference.  The box test reproduces AABB::intersect's six divisions (src/aabb.cpp:7-27) with a
+ * shorter correctly rounded sequence; this runs `pairs` pseudo-random and adversarial operand pairs through both and
+ * reports how many quotients differ (must be 0). */
+int pt_hip_selftest_division(uint64_t pairs, uint64_t seed, uint64_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -541,4 +541,35 @@ __global__ void k_sobol(DevScene sc, const uint32_t* frame_tab, const int32_t* x
     out[i] = smp.value(int(dim[i]));
 }
 
+// ------------------------------------------------------------------------------------------------ division self test
+
+// Feeds pseudo-random and adversarial operand pairs (mantissas of all ones, powers of two and their neighbours, slab-
+// like magnitudes) to div5 and counts disagreements with the division instruction sequence.
+__global__ void k_div_selftest(uint64_t seed, uint32_t per_thread, unsigned long long* mismatches) {
+    uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x + 1));
+    auto next = [&]() {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < per_thread; ++i) {
+        const uint64_t r = next();
+        uint32_t nb = uint32_t(r), db = uint32_t(r >> 32);
+        // exponents: numerator 2^-24 .. 2^24, divisor 2^-40 .. 2^1
+        const uint32_t ne = 103u + (nb >> 23) % 49u, de = 87u + (db >> 23) % 42u;
+        nb = (nb & 0x807fffffu) | (ne << 23);
+        db = (db & 0x807fffffu) | (de << 23);
+        const uint32_t kind = uint32_t(next() % 8u);
+        if (kind == 0u) db |= 0x007fffffu;                           // mantissa all ones
+        if (kind == 1u) db &= 0xff800000u;                           // power of two
+        if (kind == 2u) db = (db & 0xff800000u) | 1u;                // just above a power of two
+        if (kind == 3u) nb |= 0x007fffffu;
+        if (kind == 4u) nb = (nb & 0xff800000u) | (db & 0x007fffffu);  // equal mantissas
+        bad += div5_mismatch(as_f(nb), as_f(db));
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 }  // namespace ptd

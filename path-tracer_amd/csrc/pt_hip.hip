@@ -852,6 +852,27 @@ int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pi
     return rc;
 }
 
+int pt_hip_selftest_division(uint64_t pairs, uint64_t seed, uint64_t* mismatches) {
+    if (g_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
+    if (!mismatches) return fail(PT_ERR_INVALID, "null output");
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long)));
+    auto run = [&]() -> int {
+        HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned long long), g_stream));
+        const uint32_t threads = 256 * 1024, per_thread = uint32_t(std::max<uint64_t>(1, (pairs + threads - 1) / threads));
+        hipLaunchKernelGGL(k_div_selftest, dim3(threads / 256), dim3(256), 0, g_stream, seed, per_thread, d);
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipGetLastError());
+        unsigned long long h = 0;
+        HIP_TRY(hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost));
+        *mismatches = h;
+        return PT_OK;
+    };
+    const int rc = run();
+    (void)hipFree(d);
+    return rc;
+}
+
 int pt_hip_sobol(pt_hip_scene* s, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim, size_t n, float* out) {
     if (int rc = check_ready(s)) return rc;
     if (n == 0) return PT_OK;

@@ -7,6 +7,15 @@
 //   src/aabb.cpp:6-35   slab test with six real divisions; the z slab rejects but does not tighten the interval
 //   src/shape.cpp:50-89 Moeller-Trumbore with |det| < 1e-5 rejection and inclusive bounds on u, v, u+v and t
 //
+// The reference's slab test is not conservative: near box faces it can reject a box that contains a hit, and its
+// outcome with NaN slabs (zero direction components) is erratic.  What it reports therefore depends on exactly which
+// boxes it accepts, so BOTH modes evaluate the identical accept/reject decision, from bit-identical quotients:
+//   - box_decide() computes the six quotients with a 5-instruction correctly rounded division (reciprocal computed
+//     once per ray + two fused residual corrections); rays with a zero, tiny, huge or non-finite direction component
+//     are "special" and take the plain IEEE division so that the NaN / infinity cases come out as in the reference;
+//   - the ordered mode differs from the reference only in the ORDER in which accepted subtrees are visited and in
+//     culling by distance, and falls back to the reference order whenever order could matter (see closest_ordered_t).
+//
 // Per-lane traversal stack: the first kLdsDepth entries live in LDS, laid out [entry][lane] so that a wave's 64 lanes
 // hit 64 consecutive banks; deeper entries spill to a private (scratch) array.  The host rejects trees deeper than
 // kLdsDepth + kSpillDepth.
@@ -48,6 +57,11 @@ struct RayD {
     float tmin, tmax;
 };
 
+struct HitD {
+    int32_t prim;
+    float t, u, v;
+};
+
 // Work counters (node records fetched, triangle records fetched).  NoCount compiles to nothing; Count is used by the
 // instrumented kernel instantiations that produce the per-ray averages for the bandwidth model.
 struct NoCount {
@@ -60,57 +74,106 @@ struct Count {
     PTD void tri() { ++tris; }
 };
 
-struct HitD {
-    int32_t prim;
-    float t, u, v;
+// ------------------------------------------------------------------------------------------------ slab test
+
+// Ray with its per-axis reciprocals.  `special` marks rays whose quotients must come from the plain division.
+struct RayPre {
+    V3 o, d, y;  // y = 1 / d, correctly rounded
+    float tmin;
+    bool special;
 };
 
-// src/aabb.cpp:6-35, verbatim in behaviour (NaN compares included)
-PTD bool box_hit_ref(float4 n0, float4 n1, const RayD& r, float max_dis) {
-    const float lox = n0.x, loy = n0.y, loz = n0.z, hix = n0.w, hiy = n1.x, hiz = n1.y;
-    float tmin = (lox - r.o.x) / r.d.x;
-    float tmax = (hix - r.o.x) / r.d.x;
-    if (tmin > tmax) {
-        const float s = tmin;
-        tmin = tmax;
-        tmax = s;
+PTD RayPre make_pre(const RayD& r) {
+    RayPre p;
+    p.o = r.o;
+    p.d = r.d;
+    p.y = V3{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
+    p.tmin = r.tmin;
+    auto odd = [](float d) { return !(fabsf(d) > 1e-18f && fabsf(d) < 1e18f); };  // zero, tiny, huge, inf, NaN
+    p.special = odd(r.d.x) || odd(r.d.y) || odd(r.d.z) || !(fabsf(r.o.x) < 1e18f) || !(fabsf(r.o.y) < 1e18f) || !(fabsf(r.o.z) < 1e18f);
+    return p;
+}
+
+// n / d, correctly rounded, given y = RN(1 / d): one multiply and two residual corrections with fused multiply-adds
+// (the residual n - q*d of a quotient that is already within an ulp is exact in an FMA).  Valid for the operand range
+// make_pre() leaves non-special; a result that is not a number falls back to the division instruction sequence.
+PTD float div5(float n, float d, float y) {
+    float q = n * y;
+    float r = __fmaf_rn(-q, d, n);
+    q = __fmaf_rn(r, y, q);
+    r = __fmaf_rn(-q, d, n);
+    q = __fmaf_rn(r, y, q);
+    if (!(q == q)) q = n / d;
+    return q;
+}
+
+// AABB::intersect (src/aabb.cpp:6-35) for finite quotients: the swaps are min / max, the two early-outs and the final
+// test are the comparisons below.  `overlap` is the part that does not depend on the distance bound; `tn` is the
+// entry distance of the x/y interval that the reference compares with max_dis (the z slab never tightens it),
+// `order` = max(tn, z entry) is only used to visit the nearer child first.
+struct BoxT {
+    bool overlap;  // slabs overlap and the x/y interval ends after ray.tmin
+    float tn;      // x/y entry distance
+    float order;
+};
+
+template <bool SPECIAL>
+PTD BoxT box_decide(float lox, float loy, float loz, float hix, float hiy, float hiz, const RayPre& r) {
+    BoxT b;
+    if (SPECIAL) {
+        // verbatim control flow with IEEE divisions, so that NaN and infinity cases fall the way they do in the reference
+        float tmin = (lox - r.o.x) / r.d.x, tmax = (hix - r.o.x) / r.d.x;
+        if (tmin > tmax) {
+            const float s = tmin;
+            tmin = tmax;
+            tmax = s;
+        }
+        float tymin = (loy - r.o.y) / r.d.y, tymax = (hiy - r.o.y) / r.d.y;
+        if (tymin > tymax) {
+            const float s = tymin;
+            tymin = tymax;
+            tymax = s;
+        }
+        b.overlap = !((tmin > tymax) || (tymin > tmax));
+        if (tymin > tmin) tmin = tymin;
+        if (tymax < tmax) tmax = tymax;
+        float tzmin = (loz - r.o.z) / r.d.z, tzmax = (hiz - r.o.z) / r.d.z;
+        if (tzmin > tzmax) {
+            const float s = tzmin;
+            tzmin = tzmax;
+            tzmax = s;
+        }
+        b.overlap = b.overlap && !((tmin > tzmax) || (tzmin > tmax)) && (tmax > r.tmin);
+        b.tn = tmin;
+        b.order = (tzmin > tmin) ? tzmin : tmin;
+        return b;
     }
-    float tymin = (loy - r.o.y) / r.d.y;
-    float tymax = (hiy - r.o.y) / r.d.y;
-    if (tymin > tymax) {
-        const float s = tymin;
-        tymin = tymax;
-        tymax = s;
-    }
-    if ((tmin > tymax) || (tymin > tmax)) return false;
-    if (tymin > tmin) tmin = tymin;
-    if (tymax < tmax) tmax = tymax;
-    float tzmin = (loz - r.o.z) / r.d.z;
-    float tzmax = (hiz - r.o.z) / r.d.z;
-    if (tzmin > tzmax) {
-        const float s = tzmin;
-        tzmin = tzmax;
-        tzmax = s;
-    }
-    if ((tmin > tzmax) || (tzmin > tmax)) return false;
-    return (tmin < max_dis) && (tmax > r.tmin);
+    const float x0 = div5(lox - r.o.x, r.d.x, r.y.x), x1 = div5(hix - r.o.x, r.d.x, r.y.x);
+    const float y0 = div5(loy - r.o.y, r.d.y, r.y.y), y1 = div5(hiy - r.o.y, r.d.y, r.y.y);
+    const float z0 = div5(loz - r.o.z, r.d.z, r.y.z), z1 = div5(hiz - r.o.z, r.d.z, r.y.z);
+    const float tn = fmaxf(fminf(x0, x1), fminf(y0, y1)), tf = fminf(fmaxf(x0, x1), fmaxf(y0, y1));
+    const float zn = fminf(z0, z1), zf = fmaxf(z0, z1);
+    b.overlap = (tn <= tf) && (tn <= zf) && (zn <= tf) && (tf > r.tmin);
+    b.tn = tn;
+    b.order = fmaxf(tn, zn);
+    return b;
 }
 
 // src/shape.cpp:50-89 on a pre-gathered record {p0, e1 = p1 - p0, e2 = p2 - p0} (the subtractions are exact
 // restatements: the reference computes the same two differences per test)
-PTD bool tri_hit(V3 p0, V3 e1, V3 e2, const RayD& r, float max_dis, float& t, float& u, float& v) {
-    const V3 pvec = cross(r.d, e2);
+PTD bool tri_hit(V3 p0, V3 e1, V3 e2, const V3& o, const V3& d, float min_dis, float max_dis, float& t, float& u, float& v) {
+    const V3 pvec = cross(d, e2);
     const float det = dot(e1, pvec);
     if (det > -1e-5f && det < 1e-5f) return false;
     const float inv = 1.0f / det;
-    const V3 tvec = r.o - p0;
+    const V3 tvec = o - p0;
     u = dot(tvec, pvec) * inv;
     if (u < 0.0f || u > 1.0f) return false;
     const V3 qvec = cross(tvec, e1);
-    v = dot(r.d, qvec) * inv;
+    v = dot(d, qvec) * inv;
     if (v < 0.0f || u + v > 1.0f) return false;
     t = dot(e2, qvec) * inv;
-    return t >= r.tmin && t <= max_dis;
+    return t >= min_dis && t <= max_dis;
 }
 
 PTD void load_tri(const DevScene& sc, uint32_t slot, V3& p0, V3& e1, V3& e2, int32_t& prim) {
@@ -125,9 +188,8 @@ PTD void load_tri(const DevScene& sc, uint32_t slot, V3& p0, V3& e1, V3& e2, int
 
 // ------------------------------------------------------------------------------------------------ reference order
 
-// Closest hit in the reference's visit order.  Returns true when something was hit.
-template <class C>
-PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t* lds_stack, C& wc) {
+template <bool SPECIAL, class C>
+PTD bool closest_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre, HitD& hit, uint32_t* lds_stack, C& wc) {
     Stack st;
     st.init(lds_stack);
     st.push(0u);
@@ -149,7 +211,7 @@ PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t*
                 load_tri(sc, first + k, p0, e1, e2, prim);
                 wc.tri();
                 float t, u, v;
-                if (tri_hit(p0, e1, e2, ray, max_dis, t, u, v)) {
+                if (tri_hit(p0, e1, e2, ray.o, ray.d, ray.tmin, max_dis, t, u, v)) {
                     max_dis = t;
                     found = true;
                     hit.prim = prim;
@@ -158,17 +220,27 @@ PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t*
                     hit.v = v;
                 }
             }
-        } else if (box_hit_ref(n0, n1, ray, max_dis)) {
-            st.push(first);
-            st.push(first + 1u);
+        } else {
+            const BoxT b = box_decide<SPECIAL>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, pre);
+            if (b.overlap && b.tn < max_dis) {
+                st.push(first);
+                st.push(first + 1u);
+            }
         }
     }
     return found;
 }
 
-// Any hit in the reference's visit order; first_prim receives the first accepted triangle or -1.
+// Closest hit in the reference's visit order.  Returns true when something was hit.
 template <class C>
-PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uint32_t* lds_stack, C& wc) {
+PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t* lds_stack, C& wc) {
+    const RayPre pre = make_pre(ray);
+    if (pre.special) return closest_exact_t<true>(sc, ray, pre, hit, lds_stack, wc);
+    return closest_exact_t<false>(sc, ray, pre, hit, lds_stack, wc);
+}
+
+template <bool SPECIAL, class C>
+PTD bool any_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre, int32_t& first_prim, uint32_t* lds_stack, C& wc) {
     Stack st;
     st.init(lds_stack);
     st.push(0u);
@@ -186,98 +258,61 @@ PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uin
                 load_tri(sc, first + k, p0, e1, e2, prim);
                 wc.tri();
                 float t, u, v;
-                if (tri_hit(p0, e1, e2, ray, ray.tmax, t, u, v)) {
+                if (tri_hit(p0, e1, e2, ray.o, ray.d, ray.tmin, ray.tmax, t, u, v)) {
                     first_prim = prim;
                     return true;
                 }
             }
-        } else if (box_hit_ref(n0, n1, ray, ray.tmax)) {
-            st.push(first);
-            st.push(first + 1u);
+        } else {
+            const BoxT b = box_decide<SPECIAL>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, pre);
+            if (b.overlap && b.tn < ray.tmax) {
+                st.push(first);
+                st.push(first + 1u);
+            }
         }
     }
     return false;
+}
+
+// Any hit in the reference's visit order; first_prim receives the first accepted triangle or -1.
+template <class C>
+PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uint32_t* lds_stack, C& wc) {
+    const RayPre pre = make_pre(ray);
+    if (pre.special) return any_exact_t<true>(sc, ray, pre, first_prim, lds_stack, wc);
+    return any_exact_t<false>(sc, ray, pre, first_prim, lds_stack, wc);
 }
 
 // ------------------------------------------------------------------------------------------------ ordered, 2-wide
 
-// Conservative slab test against both child boxes of a wide node: multiplies by a reciprocal direction, ignores NaN
-// slabs (hardware min/max return the non-NaN operand) and widens the far distance by a few ulps, so that a box is
-// only rejected when no accepted hit can lie inside it.  (The reference's test is looser still: its z slab does not
-// tighten the interval.  Boxes it accepts beyond that cannot contain a nearer hit.)  near0/near1 are entry distances
-// used only for ordering.
-struct RayFast {
-    V3 o, d, rd;
-    float tmin;
-};
+// Relative width of the distance window inside which two candidates count as "equally near" for the purpose of
+// deciding whether visit order can matter (see closest_ordered_t).
+constexpr float kNearTie = 1.0f / 1024.0f;
 
-PTD void box2(const float4 w0, const float4 w1, const float4 w2, const RayFast& r, float best, bool& h0, bool& h1, float& near0,
-              float& near1) {
-    {
-        const float tx0 = (w0.x - r.o.x) * r.rd.x, tx1 = (w0.w - r.o.x) * r.rd.x;
-        const float ty0 = (w0.y - r.o.y) * r.rd.y, ty1 = (w1.x - r.o.y) * r.rd.y;
-        const float tz0 = (w0.z - r.o.z) * r.rd.z, tz1 = (w1.y - r.o.z) * r.rd.z;
-        const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), r.tmin));
-        const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), best)) * 1.000001f;
-        near0 = tn;
-        h0 = tn <= tf;
-    }
-    {
-        const float tx0 = (w1.z - r.o.x) * r.rd.x, tx1 = (w2.y - r.o.x) * r.rd.x;
-        const float ty0 = (w1.w - r.o.y) * r.rd.y, ty1 = (w2.z - r.o.y) * r.rd.y;
-        const float tz0 = (w2.x - r.o.z) * r.rd.z, tz1 = (w2.w - r.o.z) * r.rd.z;
-        const float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), r.tmin));
-        const float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), best)) * 1.000001f;
-        near1 = tn;
-        h1 = tn <= tf;
-    }
-}
-
-PTD RayFast make_fast(const RayD& ray) {
-    RayFast r;
-    r.o = ray.o;
-    r.d = ray.d;
-    // a zero direction component would give 0 * inf = NaN for an origin on a slab plane; a huge finite reciprocal gives
-    // 0 there (the ray touches the plane) and +-huge elsewhere, which keeps the test conservative
-    auto rcp = [](float d) { return fabsf(d) < 1e-30f ? copysignf(1e30f, d) : 1.0f / d; };
-    r.rd = V3{rcp(ray.d.x), rcp(ray.d.y), rcp(ray.d.z)};
-    r.tmin = ray.tmin;
-    return r;
-}
-
-// Ordered closest hit.  `tie` is set when two different triangles were accepted at the same distance: the caller then
-// re-traces the ray with closest_exact so that the winner is the one the reference's visit order picks.
-template <class C>
-PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& tie, uint32_t* lds_stack, C& wc) {
+// Ordered closest hit on the 2-wide layout.
+//
+// Same candidate set as the reference: an interior child is entered only if the reference's slab test accepts its box
+// (box_decide, identical decisions), leaf children are never box-tested (src/bvh.cpp:38-48), triangles use the same
+// test.  Differences: the nearer child is visited first, and a subtree is skipped when its x/y entry distance lies
+// beyond the current best hit by more than the kNearTie window.
+//
+// When is the result the reference's?  Let G be the nearest accepted triangle among all leaves reachable through
+// accepted boxes.  If no other candidate (and not the ray's own far end) lies within the kNearTie window of t_G, then
+// in the reference every bound that is ever compared with the entry distance of one of G's ancestors is either the
+// ray's far end or the distance of some other candidate, i.e. larger than t_G by more than the window, so the
+// reference reaches and keeps G as well.  Otherwise `redo` is set and the caller repeats the query in reference order.
+template <bool SPECIAL, class C>
+PTD bool closest_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, HitD& hit, bool& redo, uint32_t* lds_stack, C& wc) {
     Stack st;
     st.init(lds_stack);
-    const RayFast r = make_fast(ray);
-    float best = ray.tmax;
+    float best = ray.tmax;    // distance bound as the reference would hold it once the winner is found
+    float window = ray.tmax;  // candidates up to here are still looked at
+    bool near_tie = false;
     hit.prim = -1;
     hit.t = 0.0f;
     hit.u = hit.v = 0.0f;
-    tie = false;
     uint32_t cur = sc.wide_root;
     for (;;) {
-        if (!(cur & kLeafBit)) {
-            const float4* w = sc.wide + 4 * size_t(cur);
-            wc.node();
-            const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-            bool h0, h1;
-            float n0, n1;
-            box2(w0, w1, w2, r, best, h0, h1, n0, n1);
-            const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
-            if (h0 && h1) {
-                const bool swap = n1 < n0;
-                cur = swap ? r1 : r0;
-                st.push(swap ? r0 : r1);
-                continue;
-            }
-            if (h0 || h1) {
-                cur = h0 ? r0 : r1;
-                continue;
-            }
-        } else {
+        if (cur & kLeafBit) {
             const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
             for (uint32_t k = 0; k < count; ++k) {
                 V3 p0, e1, e2;
@@ -285,49 +320,74 @@ PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& tie,
                 load_tri(sc, first + k, p0, e1, e2, prim);
                 wc.tri();
                 float t, u, v;
-                if (tri_hit(p0, e1, e2, ray, best, t, u, v)) {
-                    if (t == best && hit.prim >= 0) tie = true;
-                    best = t;
-                    hit.prim = prim;
-                    hit.t = t;
-                    hit.u = u;
-                    hit.v = v;
+                if (tri_hit(p0, e1, e2, ray.o, ray.d, ray.tmin, window, t, u, v)) {
+                    // first candidate, or clearly nearer than everything seen so far: no competitor (yet);
+                    // otherwise it lies within the window of the current winner, before or behind it
+                    near_tie = !(hit.prim < 0 || t * (1.0f + kNearTie) < best);
+                    if (hit.prim < 0 || t <= best) {
+                        best = t;
+                        hit.prim = prim;
+                        hit.t = t;
+                        hit.u = u;
+                        hit.v = v;
+                        window = fminf(best * (1.0f + kNearTie), ray.tmax);
+                    }
                 }
+            }
+        } else {
+            const float4* w = sc.wide + 4 * size_t(cur);
+            wc.node();
+            const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
+            // leaf children are visited unconditionally, like the reference does; interior children by the slab test
+            bool go0 = true, go1 = true;
+            float o0 = -__builtin_huge_valf(), o1 = -__builtin_huge_valf();
+            if (!(r0 & kLeafBit)) {
+                const BoxT b = box_decide<SPECIAL>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
+                go0 = b.overlap && b.tn <= window;
+                o0 = b.order;
+            }
+            if (!(r1 & kLeafBit)) {
+                const BoxT b = box_decide<SPECIAL>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
+                go1 = b.overlap && b.tn <= window;
+                o1 = b.order;
+            }
+            if (go0 && go1) {
+                const bool swap = o1 < o0;  // leaves (order -inf) first: they can only tighten the bound
+                cur = swap ? r1 : r0;
+                st.push(swap ? r0 : r1);
+                continue;
+            }
+            if (go0 || go1) {
+                cur = go0 ? r0 : r1;
+                continue;
             }
         }
         if (st.empty()) break;
         cur = st.pop();
     }
+    // the ray's own far end counts as a competitor of the winner
+    redo = near_tie || (hit.prim >= 0 && ray.tmax < __builtin_huge_valf() && !(best * (1.0f + kNearTie) < ray.tmax));
     return hit.prim >= 0;
 }
 
-// Ordered any hit (no ordering needed for correctness; children are visited first-listed first, which is the
-// larger-area child the builder stores first for shadow rays).
 template <class C>
-PTD bool any_fast(const DevScene& sc, const RayD& ray, uint32_t* lds_stack, C& wc) {
+PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& redo, uint32_t* lds_stack, C& wc) {
+    const RayPre pre = make_pre(ray);
+    if (pre.special) return closest_ordered_t<true>(sc, ray, pre, hit, redo, lds_stack, wc);
+    return closest_ordered_t<false>(sc, ray, pre, hit, redo, lds_stack, wc);
+}
+
+// Any hit on the 2-wide layout.  The reference's distance bound is constant for this query, so the set of leaves it
+// reaches does not depend on the visit order: with identical box decisions and unconditional leaf visits this returns
+// exactly what the reference returns, whatever the order.
+template <bool SPECIAL, class C>
+PTD bool any_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, uint32_t* lds_stack, C& wc) {
     Stack st;
     st.init(lds_stack);
-    const RayFast r = make_fast(ray);
     uint32_t cur = sc.wide_root;
     for (;;) {
-        if (!(cur & kLeafBit)) {
-            const float4* w = sc.wide + 4 * size_t(cur);
-            wc.node();
-            const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-            bool h0, h1;
-            float n0, n1;
-            box2(w0, w1, w2, r, ray.tmax, h0, h1, n0, n1);
-            const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
-            if (h0 && h1) {
-                cur = r0;
-                st.push(r1);
-                continue;
-            }
-            if (h0 || h1) {
-                cur = h0 ? r0 : r1;
-                continue;
-            }
-        } else {
+        if (cur & kLeafBit) {
             const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
             for (uint32_t k = 0; k < count; ++k) {
                 V3 p0, e1, e2;
@@ -335,13 +395,55 @@ PTD bool any_fast(const DevScene& sc, const RayD& ray, uint32_t* lds_stack, C& w
                 load_tri(sc, first + k, p0, e1, e2, prim);
                 wc.tri();
                 float t, u, v;
-                if (tri_hit(p0, e1, e2, ray, ray.tmax, t, u, v)) return true;
+                if (tri_hit(p0, e1, e2, ray.o, ray.d, ray.tmin, ray.tmax, t, u, v)) return true;
+            }
+        } else {
+            const float4* w = sc.wide + 4 * size_t(cur);
+            wc.node();
+            const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
+            bool go0 = true, go1 = true;
+            if (!(r0 & kLeafBit)) {
+                const BoxT b = box_decide<SPECIAL>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
+                go0 = b.overlap && b.tn < ray.tmax;
+            }
+            if (!(r1 & kLeafBit)) {
+                const BoxT b = box_decide<SPECIAL>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
+                go1 = b.overlap && b.tn < ray.tmax;
+            }
+            if (go0 && go1) {
+                // a leaf first (cheap, may end the query); otherwise the first-listed child, which the builder made the
+                // larger one for exactly this purpose (src/bvh.cpp:137-144)
+                const bool swap = (r1 & kLeafBit) && !(r0 & kLeafBit);
+                cur = swap ? r1 : r0;
+                st.push(swap ? r0 : r1);
+                continue;
+            }
+            if (go0 || go1) {
+                cur = go0 ? r0 : r1;
+                continue;
             }
         }
         if (st.empty()) break;
         cur = st.pop();
     }
     return false;
+}
+
+template <class C>
+PTD bool any_fast(const DevScene& sc, const RayD& ray, uint32_t* lds_stack, C& wc) {
+    const RayPre pre = make_pre(ray);
+    if (pre.special) return any_ordered_t<true>(sc, ray, pre, lds_stack, wc);
+    return any_ordered_t<false>(sc, ray, pre, lds_stack, wc);
+}
+
+// ------------------------------------------------------------------------------------------------ self test
+
+// 1 when div5 differs from the division instruction sequence for this operand pair (expected: never).
+PTD uint32_t div5_mismatch(float n, float d) {
+    if (!(fabsf(d) > 1e-18f && fabsf(d) < 1e18f) || !(fabsf(n) < 1e18f)) return 0u;
+    const float a = div5(n, d, 1.0f / d), b = n / d;
+    return (as_u(a) != as_u(b) && !(a == 0.0f && b == 0.0f)) ? 1u : 0u;
 }
 
 }  // namespace ptd

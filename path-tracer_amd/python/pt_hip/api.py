@@ -116,6 +116,7 @@ def hip_lib():
         L.pt_hip_render_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
         L.pt_hip_li.argtypes = [C.c_void_p, C.POINTER(RenderParams), c_i32p, c_u32p, C.c_size_t, c_f32p, c_f32p, C.POINTER(Stats)]
         L.pt_hip_sobol.argtypes = [C.c_void_p, c_i32p, c_u32p, c_u32p, C.c_size_t, c_f32p]
+        L.pt_hip_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         _hip = L
     return _hip
 
@@ -296,6 +297,13 @@ class Scene:
         out = np.zeros(len(pix), np.float32)
         _chk(hip_lib().pt_hip_sobol(self.h, _p(pix, c_i32p), _p(smp, c_u32p), _p(dim, c_u32p), len(pix), _p(out, c_f32p)))
         return out
+
+
+def selftest_division(pairs, seed=1, device=0):
+    init(device)
+    bad = C.c_uint64(0)
+    _chk(hip_lib().pt_hip_selftest_division(pairs, seed, C.byref(bad)))
+    return bad.value
 
 
 def film_to_image(film):

@@ -1,14 +1,12 @@
-import sys
-sys.path[:0]=['path-tracer_amd/python','oracle','tests']
-import numpy as np
-from pt_hip.scene import SceneData
-from pt_hip import api
-import orc
-sd=SceneData.load('tests/golden/veach_mis_scene.npz')
-o=orc.Scene(sd); g=api.Scene(sd)
-for integ in (2,1):
-  for a,b in ((0,32),(16,17),(31,32)):
-    film,st=g.render(a,b,integrator=integ,traversal=0); want,_=o.render(a,b,integ)
-    d=np.abs(film-want); print('integ',integ,'range',a,b,'max',d.max(),'n>2e-4',int((d>2e-4).sum()),'n>1e-3',int((d>1e-3).sum()))
-    idx=np.argwhere(d>2e-4)[:6]
-    for y,x,c in idx: print('  ',y,x,c,film[y,x],want[y,x])
+import sys, os, subprocess
+# run prof_driver with alternative builds of the library (experiment)
+root=os.path.abspath(os.path.join(os.path.dirname(__file__),'..'))
+lib=os.path.join(root,'path-tracer_amd','lib','libpt_hip.so')
+import shutil
+orig=open(lib,'rb').read()
+for name in ('exp/libpt_hip_w6.so','exp/libpt_hip_w8.so'):
+    shutil.copy(os.path.join(root,'path-tracer_amd','lib',name), lib)
+    for mode in ('exact','fast'):
+        r=subprocess.run([sys.executable, os.path.join(root,'tools','prof_driver.py'),'--repeat','2','--traversal',mode],capture_output=True,text=True)
+        print(name,mode,r.stdout.strip()[-230:], r.stderr[-200:] if r.returncode else '')
+open(lib,'wb').write(orig)
