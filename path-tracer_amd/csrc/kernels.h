@@ -82,12 +82,9 @@ PTD uint32_t wave_alloc(bool want, uint32_t* counter) {
 template <class C>
 PTD bool trace_closest(const DevScene& sc, int traversal, const RayD& ray, HitD& hit, uint32_t* lds, uint32_t* retrace_counter, C& wc) {
     if (traversal == 0) return closest_exact(sc, ray, hit, lds, wc);
-    bool tie;
-    bool found = closest_fast(sc, ray, hit, tie, lds, wc);
-    if (tie) {  // two triangles at the same distance: let the reference's visit order decide
-        found = closest_exact(sc, ray, hit, lds, wc);
-        if (retrace_counter) atomicAdd(retrace_counter, 1u);
-    }
+    bool redo;  // two candidates too close for the visit order not to matter: closest_fast has repeated the query
+    const bool found = closest_fast(sc, ray, hit, redo, lds, wc);
+    if (redo && retrace_counter) atomicAdd(retrace_counter, 1u);
     return found;
 }
 

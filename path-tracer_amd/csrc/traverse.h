@@ -188,12 +188,16 @@ PTD void load_tri(const DevScene& sc, uint32_t slot, V3& p0, V3& e1, V3& e2, int
 
 // ------------------------------------------------------------------------------------------------ reference order
 
+// `bound` < +inf is only used when an ordered pass has already established that the nearest accepted triangle lies at
+// or before it: candidates and subtrees beyond the bound cannot influence which of the nearer candidates the reference
+// ends up with (they never make it skip a box that contains a nearer candidate), so leaving them out reproduces the
+// reference's result at a fraction of the work.  With bound = +inf this is the plain reference traversal.
 template <bool SPECIAL, class C>
-PTD bool closest_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre, HitD& hit, uint32_t* lds_stack, C& wc) {
+PTD bool closest_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre, float bound, HitD& hit, uint32_t* lds_stack, C& wc) {
     Stack st;
     st.init(lds_stack);
     st.push(0u);
-    float max_dis = ray.tmax;
+    float max_dis = fminf(ray.tmax, bound);
     bool found = false;
     hit.prim = -1;
     hit.t = 0.0f;
@@ -222,7 +226,7 @@ PTD bool closest_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre,
             }
         } else {
             const BoxT b = box_decide<SPECIAL>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, pre);
-            if (b.overlap && b.tn < max_dis) {
+            if (b.overlap && b.tn < max_dis && !(b.order > bound)) {
                 st.push(first);
                 st.push(first + 1u);
             }
@@ -235,8 +239,8 @@ PTD bool closest_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre,
 template <class C>
 PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t* lds_stack, C& wc) {
     const RayPre pre = make_pre(ray);
-    if (pre.special) return closest_exact_t<true>(sc, ray, pre, hit, lds_stack, wc);
-    return closest_exact_t<false>(sc, ray, pre, hit, lds_stack, wc);
+    if (pre.special) return closest_exact_t<true>(sc, ray, pre, __builtin_huge_valf(), hit, lds_stack, wc);
+    return closest_exact_t<false>(sc, ray, pre, __builtin_huge_valf(), hit, lds_stack, wc);
 }
 
 template <bool SPECIAL, class C>
@@ -286,14 +290,14 @@ PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uin
 
 // Relative width of the distance window inside which two candidates count as "equally near" for the purpose of
 // deciding whether visit order can matter (see closest_ordered_t).
-constexpr float kNearTie = 1.0f / 1024.0f;
+constexpr float kNearTie = 1.0f / 8192.0f;
 
 // Ordered closest hit on the 2-wide layout.
 //
 // Same candidate set as the reference: an interior child is entered only if the reference's slab test accepts its box
 // (box_decide, identical decisions), leaf children are never box-tested (src/bvh.cpp:38-48), triangles use the same
-// test.  Differences: the nearer child is visited first, and a subtree is skipped when its x/y entry distance lies
-// beyond the current best hit by more than the kNearTie window.
+// test.  Differences: the nearer child is visited first, and a subtree is skipped when the distance at which the ray
+// enters its box (all three slabs) lies beyond the current best hit by more than the kNearTie window.
 //
 // When is the result the reference's?  Let G be the nearest accepted triangle among all leaves reachable through
 // accepted boxes.  If no other candidate (and not the ray's own far end) lies within the kNearTie window of t_G, then
@@ -344,12 +348,12 @@ PTD bool closest_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pr
             float o0 = -__builtin_huge_valf(), o1 = -__builtin_huge_valf();
             if (!(r0 & kLeafBit)) {
                 const BoxT b = box_decide<SPECIAL>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
-                go0 = b.overlap && b.tn <= window;
+                go0 = b.overlap && b.order <= window;
                 o0 = b.order;
             }
             if (!(r1 & kLeafBit)) {
                 const BoxT b = box_decide<SPECIAL>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
-                go1 = b.overlap && b.tn <= window;
+                go1 = b.overlap && b.order <= window;
                 o1 = b.order;
             }
             if (go0 && go1) {
@@ -371,11 +375,24 @@ PTD bool closest_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pr
     return hit.prim >= 0;
 }
 
+// Ordered closest hit; when order could matter the query is repeated in reference order, bounded by twice the window
+// behind the winner the ordered pass found.
 template <class C>
 PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& redo, uint32_t* lds_stack, C& wc) {
     const RayPre pre = make_pre(ray);
-    if (pre.special) return closest_ordered_t<true>(sc, ray, pre, hit, redo, lds_stack, wc);
-    return closest_ordered_t<false>(sc, ray, pre, hit, redo, lds_stack, wc);
+    bool found;
+    if (pre.special)
+        found = closest_ordered_t<true>(sc, ray, pre, hit, redo, lds_stack, wc);
+    else
+        found = closest_ordered_t<false>(sc, ray, pre, hit, redo, lds_stack, wc);
+    if (redo) {
+        const float bound = hit.t * (1.0f + 2.0f * kNearTie);
+        if (pre.special)
+            found = closest_exact_t<true>(sc, ray, pre, bound, hit, lds_stack, wc);
+        else
+            found = closest_exact_t<false>(sc, ray, pre, bound, hit, lds_stack, wc);
+    }
+    return found;
 }
 
 // Any hit on the 2-wide layout.  The reference's distance bound is constant for this query, so the set of leaves it

@@ -101,56 +101,125 @@ def grid_plane(n=16, width=64, height=64):
     return _scene("grid%d" % n, m.v, m.t, m.m, mats, [("lamp", (30.0, 30.0, 30.0))], cam)
 
 
-def library_synth(n_books=40000, seed=0x11B4A47, width=1280, height=720):
-    """Stand-in for the missing library mesh: a room with rows of shelves filled with thin, long boxes ("books"): many
-    small axis-aligned boxes at different scales -> deep BVH, incoherent traversal.  Camera and lights follow
-    scenes/library/library.xml; materials take the three untextured parameter sets of library.mtl (Ns 100 / 5 / 360).
-    Triangle count = 12 * (n_books + shelves + 6 room/lamp boxes)."""
+def _grid_box(lo, hi, n):
+    """Axis-aligned box with every face tessellated into n x n quads: vertices (float64) and triangle indices."""
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    t = np.linspace(0.0, 1.0, n + 1)
+    a, b = np.meshgrid(t, t, indexing="ij")
+    a, b = a.ravel(), b.ravel()
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    q00, q10, q11, q01 = i * (n + 1) + j, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1, i * (n + 1) + j + 1
+    verts, tris = [], []
+    for axis in range(3):
+        u, v = (axis + 1) % 3, (axis + 2) % 3
+        for side in (0, 1):
+            p = np.zeros((len(a), 3))
+            p[:, axis] = hi[axis] if side else lo[axis]
+            p[:, u] = lo[u] + a * (hi[u] - lo[u])
+            p[:, v] = lo[v] + b * (hi[v] - lo[v])
+            base = sum(len(x) for x in verts)
+            verts.append(p)
+            if side:
+                tris.append(np.stack([q00, q10, q11], 1) + base)
+                tris.append(np.stack([q00, q11, q01], 1) + base)
+            else:
+                tris.append(np.stack([q00, q11, q10], 1) + base)
+                tris.append(np.stack([q00, q01, q11], 1) + base)
+    return np.concatenate(verts), np.concatenate(tris)
+
+
+def _icosphere(center, radius, level):
+    """Subdivided icosahedron, 20 * 4^level triangles."""
+    g = (1 + 5 ** 0.5) / 2
+    v = [(-1, g, 0), (1, g, 0), (-1, -g, 0), (1, -g, 0), (0, -1, g), (0, 1, g), (0, -1, -g), (0, 1, -g), (g, 0, -1), (g, 0, 1), (-g, 0, -1),
+         (-g, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8), (3, 9, 4),
+         (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(level):
+        cache, nf = {}, []
+
+        def mid(i, j):
+            k = (min(i, j), max(i, j))
+            if k not in cache:
+                m = v[i] + v[j]
+                v.append(m / np.linalg.norm(m))
+                cache[k] = len(v) - 1
+            return cache[k]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.asarray(center, np.float64) + radius * np.array(v), np.array(f)
+
+
+def library_synth(detail=4, seed=0x11B4A47, width=1280, height=720):
+    """Stand-in for the reference's library scene, whose mesh is not in its tree: a 4 x 2.6 x 3 m reading room, three
+    walls lined with seven-level bookcases full of books 2-4 cm thick, a table, two wall sconces (the emitters) and a
+    few globes.  Every box face is tessellated into detail x detail quads, so the triangle count scales with detail^2
+    (detail 4: about 0.45 M triangles, detail 8: about 1.8 M).  Camera and lights are those of
+    scenes/library/library.xml; the materials take the parameter sets of library.mtl (Ns 100 / 5 / 360).
+    Books stand 0.5 mm above their board and keep a gap of 8 % of their thickness, so there are no coincident faces."""
     rng = np.random.default_rng(seed)
-    m = _Mesh()
-    WALL, WOOD, BOOK_A, BOOK_B, LAMP1, LAMP2 = range(6)
+    WALL, WOOD, BOOK_A, BOOK_B, LAMP1, LAMP2, GLOBE = range(7)
     mats = [("Walls", (0.6, 0.58, 0.55), (0.0, 0.0, 0.0), 5.0), ("Wood", (0.35, 0.2, 0.1), (0.1, 0.1, 0.1), 100.0),
             ("BookA", (0.5, 0.1, 0.1), (0.05, 0.05, 0.05), 5.0), ("BookB", (0.1, 0.2, 0.4), (0.2, 0.2, 0.2), 360.0),
-            ("Sconce_Glass.001", (0.5, 0.5, 0.5), (0, 0, 0), 1.0), ("Sconce_Glass", (0.5, 0.5, 0.5), (0, 0, 0), 1.0)]
-    # room 4 x 2.6 x 3 m as an inward-facing box made of six thin slabs
+            ("Sconce_Glass.001", (0.5, 0.5, 0.5), (0, 0, 0), 1.0), ("Sconce_Glass", (0.5, 0.5, 0.5), (0, 0, 0), 1.0),
+            ("Globe", (0.3, 0.5, 0.3), (0.3, 0.3, 0.3), 100.0)]
+    V, T, M = [], [], []
+    nv = 0
+
+    def add(verts, tris, mat):
+        nonlocal nv
+        V.append(verts)
+        T.append(tris + nv)
+        M.append(np.full(len(tris), mat))
+        nv += len(verts)
+
+    def box(lo, hi, mat, n=detail):
+        add(*_grid_box(lo, hi, n), mat)
+
     X0, X1, Y0, Y1, Z0, Z1 = -2.0, 2.0, 0.0, 2.6, -1.5, 1.5
     t = 0.05
-    m.box((X0, Y0 - t, Z0), (X1, Y0, Z1), WALL)
-    m.box((X0, Y1, Z0), (X1, Y1 + t, Z1), WALL)
-    m.box((X0 - t, Y0, Z0), (X0, Y1, Z1), WALL)
-    m.box((X1, Y0, Z0), (X1 + t, Y1, Z1), WALL)
-    m.box((X0, Y0, Z0 - t), (X1, Y1, Z0), WALL)
-    m.box((X0, Y0, Z1), (X1, Y1, Z1 + t), WALL)
-    # two sconces (emitters)
-    m.box((-1.9, 1.9, 0.6), (-1.8, 2.1, 0.8), LAMP1)
-    m.box((-1.9, 1.9, -0.2), (-1.8, 2.1, 0.0), LAMP2)
-    # shelving along the -x wall and the +-z walls: boards, then books on the boards
+    big = max(2, 2 * detail)
+    box((X0, Y0 - t, Z0), (X1, Y0, Z1), WALL, big)
+    box((X0, Y1, Z0), (X1, Y1 + t, Z1), WALL, big)
+    box((X0 - t, Y0, Z0), (X0, Y1, Z1), WALL, big)
+    box((X1, Y0, Z0), (X1 + t, Y1, Z1), WALL, big)
+    box((X0, Y0, Z0 - t), (X1, Y1, Z0), WALL, big)
+    box((X0, Y0, Z1), (X1, Y1, Z1 + t), WALL, big)
+    box((-1.68, 1.9, 0.6), (-1.6, 2.1, 0.8), LAMP1, 2)           # sconces on the -x side, in front of the bookcase
+    box((-1.68, 1.9, -0.2), (-1.6, 2.1, 0.0), LAMP2, 2)
+    box((0.2, 0.72, -0.5), (1.4, 0.76, 0.5), WOOD)                # table top and legs
+    for lx, lz in ((0.25, -0.45), (1.3, -0.45), (0.25, 0.4), (1.3, 0.4)):
+        box((lx, 0.0, lz), (lx + 0.05, 0.72, lz + 0.05), WOOD, 2)
+    for c, r in (((0.5, 0.76 + 0.12, 0.1), 0.12), ((1.0, 0.76 + 0.08, -0.2), 0.08), ((-1.0, 0.15, 1.0), 0.15)):
+        add(*_icosphere(c, r, 3 if detail <= 4 else 4), GLOBE)
     boards = []
-    n_levels = 7
-    for lv in range(n_levels):
+    for lv in range(7):
         y = 0.1 + lv * 0.33
         boards.append(((X0 + 0.02, y, Z0 + 0.02), (X0 + 0.32, y + 0.02, Z1 - 0.02), 2))      # run along z
         boards.append(((X0 + 0.4, y, Z0 + 0.02), (X1 - 0.6, y + 0.02, Z0 + 0.32), 0))        # run along x
         boards.append(((X0 + 0.4, y, Z1 - 0.32), (X1 - 0.6, y + 0.02, Z1 - 0.02), 0))
-    for lo, hi, _axis in boards:
-        m.box(lo, hi, WOOD)
-    per_board = max(1, n_books // len(boards))
     for lo, hi, axis in boards:
+        box(lo, hi, WOOD)
         length = hi[axis] - lo[axis]
-        cuts = np.sort(rng.uniform(0, length, per_board + 1))
-        for k in range(per_board):
-            a, b = cuts[k], cuts[k + 1]
-            if b - a < 1e-4:
-                continue
-            hgt = rng.uniform(0.16, 0.29)
-            dep = rng.uniform(0.15, 0.27)
+        pos = 0.0
+        while True:
+            thick = rng.uniform(0.02, 0.04)
+            if pos + thick > length:
+                break
+            hgt, dep = rng.uniform(0.16, 0.29), rng.uniform(0.15, 0.27)
             blo, bhi = list(lo), list(hi)
-            blo[1], bhi[1] = hi[1], hi[1] + hgt
-            blo[axis], bhi[axis] = lo[axis] + a, lo[axis] + a + (b - a) * 0.92
+            blo[1], bhi[1] = hi[1] + 0.0005, hi[1] + 0.0005 + hgt
+            blo[axis], bhi[axis] = lo[axis] + pos, lo[axis] + pos + thick * 0.92
             o = 2 if axis == 0 else 0
             bhi[o] = blo[o] + dep
-            m.box(tuple(blo), tuple(bhi), BOOK_A if rng.random() < 0.5 else BOOK_B)
+            box(tuple(blo), tuple(bhi), BOOK_A if rng.random() < 0.5 else BOOK_B)
+            pos += thick
     cam = dict(width=width, height=height, fovy=60.0, eye=(float(np.float32(1.6146)), 1.0, float(np.float32(1.0596))),
                lookat=(float(np.float32(0.2)), float(np.float32(1.2)), float(np.float32(0.7))), up=(0.0, 1.0, 0.0))
     lights = [("Sconce_Glass.001", (26.0, 26.0, 26.0)), ("Sconce_Glass", (16.0, 14.0, 8.0))]
-    return _scene("library-synth", m.v, m.t, m.m, mats, lights, cam)
+    return _scene("library-synth", np.concatenate(V), np.concatenate(T), np.concatenate(M), mats, lights, cam)

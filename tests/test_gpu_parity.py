@@ -121,7 +121,7 @@ def test_equal_distance_hits_follow_reference_order():
 
 
 @pytest.mark.parametrize("make", [lambda: synth.random_soup(1, seed=1), lambda: synth.random_soup(7, seed=2),
-                                  lambda: synth.random_soup(3000, seed=3), synth.cornell_box, lambda: synth.library_synth(n_books=800)])
+                                  lambda: synth.random_soup(3000, seed=3), synth.cornell_box, lambda: synth.library_synth(detail=1)])
 def test_traversal_parity_synthetic_scenes(make):
     sd = make()
     o, g = orc.Scene(sd), api.Scene(sd)

@@ -32,7 +32,7 @@ def test_bvh_identical_to_oracle_veach(veach_sd):
 @pytest.mark.parametrize("make", [
     lambda: synth.random_soup(1, seed=1), lambda: synth.random_soup(2, seed=2), lambda: synth.random_soup(9, seed=3),
     lambda: synth.random_soup(1000, seed=4), lambda: synth.grid_plane(16), synth.cornell_box,
-    lambda: synth.library_synth(n_books=300)])
+    lambda: synth.library_synth(detail=1)])
 def test_bvh_identical_to_oracle_synthetic(make):
     _same_bvh(make())
 
