@@ -39,7 +39,7 @@ def load_workload(name):
     if name == "cornell-box-synth":
         return synth.cornell_box(), "cornell-box-synth (stand-in: reference mesh not in its tree) 768x768"
     if name == "library-synth":
-        sd = synth.library_synth()
+        sd = synth.library_synth(detail=8)
         return sd, "library-synth (stand-in: reference mesh not in its tree, %d tris) 1280x720" % sd.n_tris
     raise SystemExit("unknown workload " + name)
 
@@ -66,9 +66,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("PT_BENCH_WORKLOAD", "veach-mis"))
+    ap.add_argument("--workload", default=os.environ.get("PT_BENCH_WORKLOAD", "library-synth"))
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU")
-    ap.add_argument("--traversal", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--traversal", choices=["exact", "fast"], default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 

@@ -19,6 +19,7 @@
 
 #include "shade.h"
 #include "traverse.h"
+#include "traverse_wave.h"
 
 namespace ptd {
 
@@ -46,6 +47,15 @@ struct ShadowQ {
     uint32_t* count;  // [shard]
 };
 
+// Rays the wave-refill kernels hand back (plain-division rays, order-sensitive results): per shard, {queue position,
+// bits(distance bound, +inf = run the generic ordered query)}.
+struct DeferQ {
+    uint2* e;
+    uint32_t* count;  // [shard]
+};
+
+constexpr uint32_t kWaveBlocks = 8;  // workgroups per shard of a wave-refill kernel: 16 waves share a shard's queue
+
 struct PassArgs {
     const uint32_t* frame_tab;  // [frame_local][1024] Sobol' words of the sample numbers of this pass
     uint32_t spp_pass;          // samples per pixel in this pass
@@ -63,21 +73,6 @@ struct PassArgs {
 // misc[0] = exact re-traces.  Counting builds only: for kernel class k (0 generate, 1 extend, 2 shadow) the u64 at
 // word 4 + 4k holds the node records fetched and the u64 at word 6 + 4k the triangle records fetched.
 constexpr int kMiscWords = 16;
-
-PTD uint32_t lane_id() { return __lane_id(); }
-
-// Wave-level queue allocation: one atomic per wave, ballot + prefix popcount for the lane offset.
-PTD uint32_t wave_alloc(bool want, uint32_t* counter) {
-    const uint64_t mask = __ballot(want);
-    const uint32_t total = uint32_t(__popcll(mask));
-    uint32_t base = 0;
-    if (total != 0u) {
-        const int leader = __ffsll((unsigned long long)mask) - 1;
-        if (int(lane_id()) == leader) base = atomicAdd(counter, total);
-        base = uint32_t(__shfl(int(base), leader));
-    }
-    return base + uint32_t(__popcll(mask & ((1ull << lane_id()) - 1ull)));
-}
 
 template <class C>
 PTD bool trace_closest(const DevScene& sc, int traversal, const RayD& ray, HitD& hit, uint32_t* lds, uint32_t* retrace_counter, C& wc) {
@@ -251,6 +246,251 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathQ q, HitQ hq
         hq.h0[dst] = make_float4(as_f(j), as_f(uint32_t(h.prim)), h.u, h.v);
         hq.h1[dst] = make_float4(c.z, c.w, h.t, 0.0f);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ wave-refill variants
+
+// Ordered-mode extend: same inputs and outputs as k_extend, rays taken from the shard's queue through a fetch counter
+// (closest_wave).  Hits go to the hit list; deferred rays go to `dq` and are finished by k_extend_deferred.
+struct ExtendIo {
+    PathQ q;
+    HitQ hq;
+    DeferQ dq;
+    struct Carry {
+        float pix, meta;
+    };
+    PTD uint32_t count(uint32_t shard) const { return q.count[shard]; }
+    PTD void load(uint32_t shard, uint32_t j, RayD& ray, Carry& c) const {
+        const size_t i = size_t(shard) * kShard + j;
+        const float4 a = q.a[i], b = q.b[i], cc = q.c[i];
+        ray = RayD{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
+        c.pix = cc.z;
+        c.meta = cc.w;
+    }
+    PTD void commit(uint32_t shard, bool fin, uint32_t j, const HitD& h, bool defer, float bound, const Carry& c) const {
+        const size_t sbase = size_t(shard) * kShard;
+        const bool found = fin && !defer && h.prim >= 0;
+        const uint32_t local = wave_alloc(found, hq.count + shard);
+        if (found) {
+            hq.h0[sbase + local] = make_float4(as_f(j), as_f(uint32_t(h.prim)), h.u, h.v);
+            hq.h1[sbase + local] = make_float4(c.pix, c.meta, h.t, 0.0f);
+        }
+        const bool d = fin && defer;
+        if (__any(d)) {
+            const uint32_t dl = wave_alloc(d, dq.count + shard);
+            if (d) dq.e[sbase + dl] = make_uint2(j, as_u(bound));
+        }
+    }
+};
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_extend_wave(DevScene sc, ExtendIo io, uint32_t* fetch, uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    C wc;
+    closest_wave(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
+    flush_counts(wc, misc, 1);
+}
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_extend_deferred(DevScene sc, PathQ q, HitQ hq, DeferQ dq, uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t shard = blockIdx.y;
+    const size_t sbase = size_t(shard) * kShard;
+    const uint32_t n = dq.count[shard];
+    C wc;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const uint32_t k = base + threadIdx.x;
+        bool found = false;
+        HitD h{-1, 0.0f, 0.0f, 0.0f};
+        uint32_t j = 0;
+        float4 c{};
+        if (k < n) {
+            const uint2 e = dq.e[sbase + k];
+            j = e.x;
+            const float bound = as_f(e.y);
+            const float4 a = q.a[sbase + j], b = q.b[sbase + j];
+            c = q.c[sbase + j];
+            const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
+            bool redo = true;
+            if (bound == __builtin_huge_valf()) {
+                found = closest_fast(sc, ray, h, redo, s_stack + threadIdx.x, wc);
+            } else {
+                const RayPre pre = make_pre(sc, ray);
+                found = closest_exact_t<false>(sc, ray, pre, bound, h, s_stack + threadIdx.x, wc);
+            }
+            if (redo && misc) atomicAdd(misc, 1u);
+        }
+        const uint32_t local = wave_alloc(found, hq.count + shard);
+        if (found) {
+            hq.h0[sbase + local] = make_float4(as_f(j), as_f(uint32_t(h.prim)), h.u, h.v);
+            hq.h1[sbase + local] = make_float4(c.z, c.w, h.t, 0.0f);
+        }
+    }
+    flush_counts(wc, misc, 1);
+}
+
+// Ordered-mode shadow: same inputs and outputs as k_shadow (any_wave); plain-division rays go to `dq`.
+struct ShadowIo {
+    ShadowQ sh;
+    DeferQ dq;
+    float4* lbuf;
+    struct Carry {
+        uint32_t slot;
+    };
+    PTD uint32_t count(uint32_t shard) const { return sh.count[shard]; }
+    PTD void load(uint32_t shard, uint32_t j, RayD& ray, Carry& c) const {
+        const size_t i = size_t(shard) * kShard + j;
+        const float4 a = sh.a[i], b = sh.b[i];
+        ray = RayD{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
+        c.slot = as_u(b.w);
+    }
+    PTD void commit(uint32_t shard, bool fin, uint32_t j, bool occluded, bool defer, const Carry& c) const {
+        const size_t sbase = size_t(shard) * kShard;
+        if (fin && !defer && !occluded) {
+            const float4 v = sh.c[sbase + j];
+            float4 L = lbuf[c.slot];
+            L.x += v.x;
+            L.y += v.y;
+            L.z += v.z;
+            lbuf[c.slot] = L;
+        }
+        const bool d = fin && defer;
+        if (__any(d)) {
+            const uint32_t dl = wave_alloc(d, dq.count + shard);
+            if (d) dq.e[sbase + dl] = make_uint2(j, 0u);
+        }
+    }
+};
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_shadow_wave(DevScene sc, ShadowIo io, uint32_t* fetch, uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    C wc;
+    any_wave(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
+    flush_counts(wc, misc, 2);
+}
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_shadow_deferred(DevScene sc, ShadowQ sh, DeferQ dq, float4* lbuf, uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t shard = blockIdx.y;
+    const size_t sbase = size_t(shard) * kShard;
+    const uint32_t n = dq.count[shard];
+    C wc;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        const uint32_t j = dq.e[sbase + k].x;
+        const float4 a = sh.a[sbase + j], b = sh.b[sbase + j];
+        const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
+        if (!any_fast(sc, ray, s_stack + threadIdx.x, wc)) {
+            const float4 v = sh.c[sbase + j];
+            const uint32_t slot = as_u(b.w);
+            float4 L = lbuf[slot];
+            L.x += v.x;
+            L.y += v.y;
+            L.z += v.z;
+            lbuf[slot] = L;
+        }
+    }
+    flush_counts(wc, misc, 2);
+}
+
+// Ordered-mode batched queries: the batch is cut into shards of kShard rays, each with its own fetch counter.  Deferred
+// rays are marked in the output (prim = kBatchDeferred, t = bound; occluded = 2) and finished by the *_fix kernels.
+constexpr uint32_t kBatchDeferred = 0xfffffffeu;
+
+struct BatchClosestIo {
+    const float4* rays;
+    uint32_t n;
+    float4* hits;
+    struct Carry {};
+    PTD uint32_t count(uint32_t shard) const { return min(kShard, n - shard * kShard); }
+    PTD void load(uint32_t shard, uint32_t j, RayD& ray, Carry&) const {
+        const size_t i = size_t(shard) * kShard + j;
+        const float4 r0 = rays[2 * i], r1 = rays[2 * i + 1];
+        ray = RayD{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
+    }
+    PTD void commit(uint32_t shard, bool fin, uint32_t j, const HitD& h, bool defer, float bound, const Carry&) const {
+        if (!fin) return;
+        const size_t i = size_t(shard) * kShard + j;
+        hits[i] = defer ? make_float4(as_f(kBatchDeferred), bound, 0.0f, 0.0f) : make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+    }
+};
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_intersect_wave(DevScene sc, BatchClosestIo io, uint32_t* fetch, uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    C wc;
+    closest_wave(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
+    flush_counts(wc, misc, 1);
+}
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_intersect_fix(DevScene sc, const float4* rays, uint32_t n, float4* hits, uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    C wc;
+    if (i < n) {
+        const float4 m = hits[i];
+        if (as_u(m.x) == kBatchDeferred) {
+            const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
+            const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
+            HitD h;
+            bool redo = true;
+            if (m.y == __builtin_huge_valf()) {
+                closest_fast(sc, ray, h, redo, s_stack + threadIdx.x, wc);
+            } else {
+                const RayPre pre = make_pre(sc, ray);
+                closest_exact_t<false>(sc, ray, pre, m.y, h, s_stack + threadIdx.x, wc);
+            }
+            if (redo && misc) atomicAdd(misc, 1u);
+            hits[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+        }
+    }
+    flush_counts(wc, misc, 1);
+}
+
+struct BatchAnyIo {
+    const float4* rays;
+    uint32_t n;
+    uint8_t* occ;
+    struct Carry {};
+    PTD uint32_t count(uint32_t shard) const { return min(kShard, n - shard * kShard); }
+    PTD void load(uint32_t shard, uint32_t j, RayD& ray, Carry&) const {
+        const size_t i = size_t(shard) * kShard + j;
+        const float4 r0 = rays[2 * i], r1 = rays[2 * i + 1];
+        ray = RayD{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
+    }
+    PTD void commit(uint32_t shard, bool fin, uint32_t j, bool occluded, bool defer, const Carry&) const {
+        if (fin) occ[size_t(shard) * kShard + j] = defer ? uint8_t(2) : uint8_t(occluded ? 1 : 0);
+    }
+};
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_occluded_wave(DevScene sc, BatchAnyIo io, uint32_t* fetch, uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    C wc;
+    any_wave(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
+    flush_counts(wc, misc, 2);
+}
+
+// finishes deferred rays and fills first_prim (ordered mode has no "first found" triangle: -2 for occluded rays)
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_occluded_fix(DevScene sc, const float4* rays, uint32_t n, uint8_t* occ, int32_t* first_prim,
+                                                          uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    C wc;
+    if (i < n) {
+        uint8_t o = occ[i];
+        if (o == 2) {
+            const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
+            const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
+            o = any_fast(sc, ray, s_stack + threadIdx.x, wc) ? 1 : 0;
+            occ[i] = o;
+        }
+        if (first_prim) first_prim[i] = o ? -2 : -1;
+    }
+    flush_counts(wc, misc, 2);
 }
 
 // ------------------------------------------------------------------------------------------------ shade
@@ -541,7 +781,7 @@ __global__ void k_sobol(DevScene sc, const uint32_t* frame_tab, const int32_t* x
 // ------------------------------------------------------------------------------------------------ division self test
 
 // Feeds pseudo-random and adversarial operand pairs (mantissas of all ones, powers of two and their neighbours, slab-
-// like magnitudes) to div5 and counts disagreements with the division instruction sequence.
+// like magnitudes) to div_refine and counts disagreements with the division instruction sequence.
 __global__ void k_div_selftest(uint64_t seed, uint32_t per_thread, unsigned long long* mismatches) {
     uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x + 1));
     auto next = [&]() {
@@ -554,8 +794,8 @@ __global__ void k_div_selftest(uint64_t seed, uint32_t per_thread, unsigned long
     for (uint32_t i = 0; i < per_thread; ++i) {
         const uint64_t r = next();
         uint32_t nb = uint32_t(r), db = uint32_t(r >> 32);
-        // exponents: numerator 2^-24 .. 2^24, divisor 2^-40 .. 2^1
-        const uint32_t ne = 103u + (nb >> 23) % 49u, de = 87u + (db >> 23) % 42u;
+        // exponents: numerator 2^-60 .. 2^49, divisor 2^-29 .. 2^1 (pairs outside the range the traversal uses are skipped)
+        const uint32_t ne = 67u + (nb >> 23) % 110u, de = 98u + (db >> 23) % 31u;
         nb = (nb & 0x807fffffu) | (ne << 23);
         db = (db & 0x807fffffu) | (de << 23);
         const uint32_t kind = uint32_t(next() % 8u);

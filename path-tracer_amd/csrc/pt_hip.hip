@@ -26,6 +26,8 @@ thread_local std::string g_error;
 int g_device = -1;
 hipStream_t g_stream = nullptr;
 
+constexpr uint32_t kMaxGridY = 65535;
+
 int fail(int code, const std::string& msg) {
     g_error = msg;
     return code;
@@ -74,15 +76,19 @@ struct Workspace {
     PathQ q[2]{};
     HitQ hq{};
     ShadowQ sh{};
+    DeferQ dqe{}, dqs{};  // rays handed back by the wave-refill extend / shadow kernels
     float4* lbuf = nullptr;
-    // device counters: [q0 | q1 | shadow | hit] of n_shards words each, then kMiscWords
+    // device counters, n_shards words each: [q0 | q1 | hit | shadow | fetch extend | fetch shadow | deferred extend |
+    // deferred shadow], then kMiscWords
+    uint32_t* fetch_e = nullptr;
+    uint32_t* fetch_s = nullptr;
     uint32_t* counters = nullptr;
     uint32_t* h_counters = nullptr;  // pinned host mirror
     uint32_t* misc = nullptr;
     uint32_t* frame_tab = nullptr;
     size_t frame_cap = 0;  // in frames
     std::vector<void*> owned;
-    size_t counter_words() const { return size_t(4) * n_shards + kMiscWords; }
+    size_t counter_words() const { return size_t(8) * n_shards + kMiscWords; }
 };
 
 struct EventPool {
@@ -101,6 +107,8 @@ struct pt_hip_scene {
     uint32_t width = 0, height = 0;
     Workspace ws;
     EventPool events;
+    uint32_t* batch_fetch = nullptr;  // per-shard fetch counters of the batched ordered queries
+    size_t batch_fetch_cap = 0;
 };
 
 namespace {
@@ -295,6 +303,12 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     }
     dev.n_tris = d->n_tris;
     dev.n_lights = d->n_lights;
+    {
+        const pt_bvh_node& root = d->nodes[0];
+        float m = 0.0f;
+        for (int a = 0; a < 3; ++a) m = std::max(m, std::max(std::fabs(root.lo[a]), std::fabs(root.hi[a])));
+        dev.all_special = (m < 0x1p59f) ? 0u : 1u;  // also 1 when a bound is not a number
+    }
     // camera
     std::memcpy(dev.cam.s2c, d->camera.sample2camera, 64);
     std::memcpy(dev.cam.c2w, d->camera.camera2world, 64);
@@ -360,6 +374,7 @@ void ws_release(Workspace& ws) {
 
 int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
     const uint32_t n_shards = (n_slots + kShard - 1) / kShard;
+    if (n_shards > kMaxGridY) return fail(PT_ERR_LIMIT, "too many samples in flight for one pass: lower samples_per_pass");
     const uint32_t padded = n_shards * kShard;
     if (padded > ws.cap_slots || n_frames > ws.frame_cap) {
         ws_release(ws);
@@ -375,6 +390,8 @@ int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
         if (int rc = ws_alloc(ws, &ws.sh.a, padded)) return rc;
         if (int rc = ws_alloc(ws, &ws.sh.b, padded)) return rc;
         if (int rc = ws_alloc(ws, &ws.sh.c, padded)) return rc;
+        if (int rc = ws_alloc(ws, &ws.dqe.e, padded)) return rc;
+        if (int rc = ws_alloc(ws, &ws.dqs.e, padded)) return rc;
         if (int rc = ws_alloc(ws, &ws.lbuf, padded)) return rc;
         if (int rc = ws_alloc(ws, &ws.counters, ws.counter_words())) return rc;
         if (int rc = ws_alloc(ws, &ws.frame_tab, n_frames * 1024)) return rc;
@@ -386,9 +403,13 @@ int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
     ws.n_shards = n_shards;
     ws.q[0].count = ws.counters;
     ws.q[1].count = ws.counters + n_shards;
-    ws.sh.count = ws.counters + 2 * size_t(n_shards);
-    ws.hq.count = ws.counters + 3 * size_t(n_shards);
-    ws.misc = ws.counters + 4 * size_t(n_shards);
+    ws.hq.count = ws.counters + 2 * size_t(n_shards);
+    ws.sh.count = ws.counters + 3 * size_t(n_shards);
+    ws.fetch_e = ws.counters + 4 * size_t(n_shards);
+    ws.fetch_s = ws.counters + 5 * size_t(n_shards);
+    ws.dqe.count = ws.counters + 6 * size_t(n_shards);
+    ws.dqs.count = ws.counters + 7 * size_t(n_shards);
+    ws.misc = ws.counters + 8 * size_t(n_shards);
     return PT_OK;
 }
 
@@ -435,7 +456,7 @@ struct Timer {
     }
 };
 
-inline uint32_t blocks(uint32_t n, uint32_t b) { return (n + b - 1) / b; }
+inline uint32_t blocks(uint32_t n, uint32_t b) { return uint32_t((uint64_t(n) + b - 1) / b); }
 
 struct Fill {
     uint32_t max = 0;
@@ -470,42 +491,67 @@ int launch_generate(pt_hip_scene* s, const PassArgs& pa, Timer& tm, bool count) 
 int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bool count) {
     Workspace& ws = s->ws;
     const uint32_t K = ws.n_shards;
-    HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, ws.counter_words() * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * size_t(K) * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
-    Fill hits = fill_of(ws.h_counters + 3 * size_t(K), K);
+    Fill hits = fill_of(ws.h_counters + 2 * size_t(K), K);
     int cur = 0;
+    const bool wave = pa.traversal == PT_TRAVERSE_FAST;
     // every loop iteration is one bounce; specular chains do not advance the bounce counter (src/integrator.cpp:84-87),
     // so bound the loop independently
     for (uint32_t iter = 0; hits.max > 0 && iter < 8 * pa.max_bounce; ++iter) {
         const int nxt = cur ^ 1;
         HIP_TRY(hipMemsetAsync(ws.q[nxt].count, 0, K * sizeof(uint32_t), g_stream));
-        HIP_TRY(hipMemsetAsync(ws.sh.count, 0, K * sizeof(uint32_t), g_stream));
+        HIP_TRY(hipMemsetAsync(ws.sh.count, 0, 5 * size_t(K) * sizeof(uint32_t), g_stream));  // shadow, both fetch, both deferred
         if (int rc = tm.begin(PT_K_SHADE)) return rc;
         hipLaunchKernelGGL(k_shade, dim3(blocks(hits.max, 256), K), dim3(256), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.q[nxt], ws.sh,
                            ws.lbuf);
         if (int rc = tm.end()) return rc;
         HIP_TRY(hipMemsetAsync(ws.hq.count, 0, K * sizeof(uint32_t), g_stream));
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 3 * size_t(K) * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * size_t(K) * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
-        const Fill next = fill_of(ws.h_counters + size_t(nxt) * K, K), shadow = fill_of(ws.h_counters + 2 * size_t(K), K);
+        const Fill next = fill_of(ws.h_counters + size_t(nxt) * K, K), shadow = fill_of(ws.h_counters + 3 * size_t(K), K);
         if (shadow.max) {
             if (int rc = tm.begin(PT_K_SHADOW)) return rc;
-            if (count)
+            if (wave) {
+                const dim3 grid(std::min(kWaveBlocks, blocks(shadow.max, kBlock)), K);
+                const ShadowIo io{ws.sh, ws.dqs, ws.lbuf};
+                if (count) {
+                    hipLaunchKernelGGL(k_shadow_wave<Count>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_s, ws.misc);
+                    hipLaunchKernelGGL(k_shadow_deferred<Count>, dim3(1, K), dim3(kBlock), 0, g_stream, s->dev, ws.sh, ws.dqs, ws.lbuf, ws.misc);
+                } else {
+                    hipLaunchKernelGGL(k_shadow_wave<NoCount>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_s, ws.misc);
+                    hipLaunchKernelGGL(k_shadow_deferred<NoCount>, dim3(1, K), dim3(kBlock), 0, g_stream, s->dev, ws.sh, ws.dqs, ws.lbuf,
+                                       ws.misc);
+                }
+            } else if (count) {
                 hipLaunchKernelGGL(k_shadow<Count>, dim3(blocks(shadow.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.sh, pa.traversal,
                                    ws.lbuf, ws.misc);
-            else
+            } else {
                 hipLaunchKernelGGL(k_shadow<NoCount>, dim3(blocks(shadow.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.sh,
                                    pa.traversal, ws.lbuf, ws.misc);
+            }
             if (int rc = tm.end()) return rc;
         }
         if (next.max) {
             if (int rc = tm.begin(PT_K_EXTEND)) return rc;
-            if (count)
+            if (wave) {
+                const dim3 grid(std::min(kWaveBlocks, blocks(next.max, kBlock)), K);
+                const ExtendIo io{ws.q[nxt], ws.hq, ws.dqe};
+                if (count) {
+                    hipLaunchKernelGGL(k_extend_wave<Count>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_e, ws.misc);
+                    hipLaunchKernelGGL(k_extend_deferred<Count>, dim3(1, K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], ws.hq, ws.dqe, ws.misc);
+                } else {
+                    hipLaunchKernelGGL(k_extend_wave<NoCount>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_e, ws.misc);
+                    hipLaunchKernelGGL(k_extend_deferred<NoCount>, dim3(1, K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], ws.hq, ws.dqe,
+                                       ws.misc);
+                }
+            } else if (count) {
                 hipLaunchKernelGGL(k_extend<Count>, dim3(blocks(next.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], ws.hq,
                                    pa.traversal, ws.misc);
-            else
+            } else {
                 hipLaunchKernelGGL(k_extend<NoCount>, dim3(blocks(next.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], ws.hq,
                                    pa.traversal, ws.misc);
+            }
             if (int rc = tm.end()) return rc;
         }
         if (st) {
@@ -523,6 +569,60 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
 int check_ready(const pt_hip_scene* s) {
     if (g_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
     if (!s) return fail(PT_ERR_INVALID, "scene handle is null");
+    return PT_OK;
+}
+
+// zeroed fetch counters for a batch of n rays cut into shards of kShard
+int batch_fetch_reserve(pt_hip_scene* s, uint32_t n_shards) {
+    if (n_shards > s->batch_fetch_cap) {
+        if (s->batch_fetch) (void)hipFree(s->batch_fetch);
+        s->batch_fetch = nullptr;
+        s->batch_fetch_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->batch_fetch), size_t(n_shards) * sizeof(uint32_t)));
+        s->batch_fetch_cap = n_shards;
+    }
+    HIP_TRY(hipMemsetAsync(s->batch_fetch, 0, size_t(n_shards) * sizeof(uint32_t), g_stream));
+    return PT_OK;
+}
+
+int launch_intersect(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_hit* d_hits, int mode) {
+    const float4* rays = reinterpret_cast<const float4*>(d_rays);
+    float4* hits = reinterpret_cast<float4*>(d_hits);
+    if (mode == PT_TRAVERSE_FAST) {
+        const uint32_t n_shards = blocks(uint32_t(n), kShard);
+        if (int rc = batch_fetch_reserve(s, n_shards)) return rc;
+        for (uint32_t s0 = 0; s0 < n_shards; s0 += kMaxGridY) {  // grid.y is limited to 65535
+            const size_t off = size_t(s0) * kShard;
+            const BatchClosestIo io{rays + 2 * off, uint32_t(std::min<size_t>(n - off, size_t(kMaxGridY) * kShard)), hits + off};
+            hipLaunchKernelGGL(k_intersect_wave<NoCount>, dim3(std::min(kWaveBlocks, blocks(io.n, kBlock)), blocks(io.n, kShard)), dim3(kBlock),
+                               0, g_stream, s->dev, io, s->batch_fetch + s0, (uint32_t*)nullptr);
+        }
+        hipLaunchKernelGGL(k_intersect_fix<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev, rays, uint32_t(n),
+                           hits, (uint32_t*)nullptr);
+    } else {
+        hipLaunchKernelGGL(k_intersect<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev, rays, uint32_t(n), hits,
+                           mode, (uint32_t*)nullptr);
+    }
+    return PT_OK;
+}
+
+int launch_occluded(pt_hip_scene* s, const pt_ray* d_rays, size_t n, uint8_t* d_occ, int32_t* d_first, int mode) {
+    const float4* rays = reinterpret_cast<const float4*>(d_rays);
+    if (mode == PT_TRAVERSE_FAST) {
+        const uint32_t n_shards = blocks(uint32_t(n), kShard);
+        if (int rc = batch_fetch_reserve(s, n_shards)) return rc;
+        for (uint32_t s0 = 0; s0 < n_shards; s0 += kMaxGridY) {
+            const size_t off = size_t(s0) * kShard;
+            const BatchAnyIo io{rays + 2 * off, uint32_t(std::min<size_t>(n - off, size_t(kMaxGridY) * kShard)), d_occ + off};
+            hipLaunchKernelGGL(k_occluded_wave<NoCount>, dim3(std::min(kWaveBlocks, blocks(io.n, kBlock)), blocks(io.n, kShard)), dim3(kBlock),
+                               0, g_stream, s->dev, io, s->batch_fetch + s0, (uint32_t*)nullptr);
+        }
+        hipLaunchKernelGGL(k_occluded_fix<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev, rays, uint32_t(n),
+                           d_occ, d_first, (uint32_t*)nullptr);
+    } else {
+        hipLaunchKernelGGL(k_occluded<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev, rays, uint32_t(n), d_occ,
+                           d_first, mode, (uint32_t*)nullptr);
+    }
     return PT_OK;
 }
 
@@ -591,6 +691,7 @@ int pt_hip_scene_destroy(pt_hip_scene* s) {
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     ws_release(s->ws);
     for (hipEvent_t e : s->events.ev) (void)hipEventDestroy(e);
+    if (s->batch_fetch) (void)hipFree(s->batch_fetch);
     for (void* p : s->owned) (void)hipFree(p);
     delete s;
     return PT_OK;
@@ -605,8 +706,7 @@ int pt_hip_intersect_device(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, g_stream));
-    hipLaunchKernelGGL(k_intersect<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
-                       reinterpret_cast<const float4*>(d_rays), uint32_t(n), reinterpret_cast<float4*>(d_hits), mode, (uint32_t*)nullptr);
+    if (int rc = launch_intersect(s, d_rays, n, d_hits, mode)) return rc;
     HIP_TRY(hipEventRecord(e1, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     HIP_TRY(hipGetLastError());
@@ -627,8 +727,7 @@ int pt_hip_occluded_device(pt_hip_scene* s, const pt_ray* d_rays, size_t n, uint
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, g_stream));
-    hipLaunchKernelGGL(k_occluded<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
-                       reinterpret_cast<const float4*>(d_rays), uint32_t(n), d_occ, (int32_t*)nullptr, mode, (uint32_t*)nullptr);
+    if (int rc = launch_occluded(s, d_rays, n, d_occ, nullptr, mode)) return rc;
     HIP_TRY(hipEventRecord(e1, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     HIP_TRY(hipGetLastError());
@@ -682,9 +781,9 @@ int pt_hip_occluded(pt_hip_scene* s, const pt_ray* rays, size_t n, uint8_t* occl
     }
     if (hipMemcpy(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice) != hipSuccess) rc = fail(PT_ERR_DEVICE, "ray upload failed");
     if (!rc) {
-        hipLaunchKernelGGL(k_occluded<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev,
-                           reinterpret_cast<const float4*>(d_rays), uint32_t(n), d_occ, d_first, mode, (uint32_t*)nullptr);
-        if (hipStreamSynchronize(g_stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(PT_ERR_DEVICE, "k_occluded failed");
+        rc = launch_occluded(s, d_rays, n, d_occ, d_first, mode);
+        if (rc) {
+        } else if (hipStreamSynchronize(g_stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(PT_ERR_DEVICE, "k_occluded failed");
     }
     if (!rc && hipMemcpy(occluded, d_occ, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PT_ERR_DEVICE, "download failed");
     if (!rc && first_prim && hipMemcpy(first_prim, d_first, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)

@@ -58,6 +58,7 @@ struct DevScene {
     const DevTexture* textures;
     const float* tex_data;
     uint32_t n_tris, n_lights;
+    uint32_t all_special;  // scene bounds too large for the fast slab arithmetic: every ray takes the plain division
     DevCamera cam;
     // ---- Sobol' sampler: word(dim) = F[frame][dim] ^ X[px][dim] ^ Y[py][dim]  (all XOR-linear in the index bits);
     //      rows of 1024 words, so the consecutive dimensions of one bounce sit in one cache line per table

@@ -11,8 +11,9 @@
 // outcome with NaN slabs (zero direction components) is erratic.  What it reports therefore depends on exactly which
 // boxes it accepts, so BOTH modes evaluate the identical accept/reject decision, from bit-identical quotients:
 //   - box_decide() computes the six quotients with a 5-instruction correctly rounded division (reciprocal computed
-//     once per ray + two fused residual corrections); rays with a zero, tiny, huge or non-finite direction component
-//     are "special" and take the plain IEEE division so that the NaN / infinity cases come out as in the reference;
+//     once per ray, one multiply, two fused residual corrections); rays with a zero, tiny, huge or non-finite direction
+//     component are "special" and take the plain IEEE division so that the NaN / infinity cases come out as in the
+//     reference, and so does any box for which one of the quotient estimates is zero or tiny;
 //   - the ordered mode differs from the reference only in the ORDER in which accepted subtrees are visited and in
 //     culling by distance, and falls back to the reference order whenever order could matter (see closest_ordered_t).
 //
@@ -30,12 +31,18 @@ constexpr int kLdsDepth = 24;    // stack entries per lane in LDS
 constexpr int kSpillDepth = 72;  // further entries per lane in scratch
 constexpr int kMaxStack = kLdsDepth + kSpillDepth;
 
+// Explicit address spaces: with generic pointers the compiler merges the two arms of pop() into one flat load.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(5))) uint32_t private_u32;
+
 struct Stack {
-    uint32_t* lds;  // &shared[0][threadIdx.x]
-    uint32_t spill[kSpillDepth];
+    lds_u32* lds;        // &shared[0][threadIdx.x]
+    private_u32* spill;  // kSpillDepth private words, declared by the function that owns the stack (kept out of this
+                         // struct so that the compiler keeps everything but the array itself in registers)
     int sp;
-    PTD void init(uint32_t* base) {
-        lds = base;
+    PTD void init(uint32_t* base, uint32_t* spill_words) {
+        lds = (lds_u32*)base;
+        spill = (private_u32*)spill_words;
         sp = 0;
     }
     PTD void push(uint32_t v) {
@@ -83,28 +90,31 @@ struct RayPre {
     bool special;
 };
 
-PTD RayPre make_pre(const RayD& r) {
+// Operand ranges for which the multiply-and-refine division (div_refine) is used.  Direction components within 2^-30 .. 2^30 in magnitude, origin and scene
+// coordinates below 2^59: then no product overflows, and as long as the first estimate of a quotient is at least kTinyQ in
+// magnitude every residual is a multiple of 2^-149, i.e. exact.  Everything else takes the division instruction.
+constexpr float kDirLo = 0x1p-30f, kDirHi = 0x1p30f, kCoordHi = 0x1p59f, kTinyQ = 0x1p-60f;
+
+PTD RayPre make_pre(const DevScene& sc, const RayD& r) {
     RayPre p;
     p.o = r.o;
     p.d = r.d;
     p.y = V3{1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z};
     p.tmin = r.tmin;
-    auto odd = [](float d) { return !(fabsf(d) > 1e-18f && fabsf(d) < 1e18f); };  // zero, tiny, huge, inf, NaN
-    p.special = odd(r.d.x) || odd(r.d.y) || odd(r.d.z) || !(fabsf(r.o.x) < 1e18f) || !(fabsf(r.o.y) < 1e18f) || !(fabsf(r.o.z) < 1e18f);
+    auto odd = [](float d) { return !(fabsf(d) > kDirLo && fabsf(d) < kDirHi); };  // zero, tiny, huge, inf, NaN
+    p.special = sc.all_special != 0u || odd(r.d.x) || odd(r.d.y) || odd(r.d.z) || !(fabsf(r.o.x) < kCoordHi) || !(fabsf(r.o.y) < kCoordHi) ||
+                !(fabsf(r.o.z) < kCoordHi);
     return p;
 }
 
-// n / d, correctly rounded, given y = RN(1 / d): one multiply and two residual corrections with fused multiply-adds
-// (the residual n - q*d of a quotient that is already within an ulp is exact in an FMA).  Valid for the operand range
-// make_pre() leaves non-special; a result that is not a number falls back to the division instruction sequence.
-PTD float div5(float n, float d, float y) {
-    float q = n * y;
-    float r = __fmaf_rn(-q, d, n);
-    q = __fmaf_rn(r, y, q);
+// n / d, correctly rounded, from the estimate p = n * y with y = RN(1 / d): two residual corrections with fused
+// multiply-adds (the residual n - q*d of a quotient that is already within an ulp is exact in an FMA).  Valid for the
+// operand ranges above; callers check |p| >= kTinyQ.
+PTD float div_refine(float p, float n, float d, float y) {
+    float r = __fmaf_rn(-p, d, n);
+    float q = __fmaf_rn(r, y, p);
     r = __fmaf_rn(-q, d, n);
-    q = __fmaf_rn(r, y, q);
-    if (!(q == q)) q = n / d;
-    return q;
+    return __fmaf_rn(r, y, q);
 }
 
 // AABB::intersect (src/aabb.cpp:6-35) for finite quotients: the swaps are min / max, the two early-outs and the final
@@ -148,9 +158,13 @@ PTD BoxT box_decide(float lox, float loy, float loz, float hix, float hiy, float
         b.order = (tzmin > tmin) ? tzmin : tmin;
         return b;
     }
-    const float x0 = div5(lox - r.o.x, r.d.x, r.y.x), x1 = div5(hix - r.o.x, r.d.x, r.y.x);
-    const float y0 = div5(loy - r.o.y, r.d.y, r.y.y), y1 = div5(hiy - r.o.y, r.d.y, r.y.y);
-    const float z0 = div5(loz - r.o.z, r.d.z, r.y.z), z1 = div5(hiz - r.o.z, r.d.z, r.y.z);
+    const float nx0 = lox - r.o.x, nx1 = hix - r.o.x, ny0 = loy - r.o.y, ny1 = hiy - r.o.y, nz0 = loz - r.o.z, nz1 = hiz - r.o.z;
+    const float px0 = nx0 * r.y.x, px1 = nx1 * r.y.x, py0 = ny0 * r.y.y, py1 = ny1 * r.y.y, pz0 = nz0 * r.y.z, pz1 = nz1 * r.y.z;
+    const float smallest = fminf(fminf(fminf(fabsf(px0), fabsf(px1)), fminf(fabsf(py0), fabsf(py1))), fminf(fabsf(pz0), fabsf(pz1)));
+    if (!(smallest >= kTinyQ)) return box_decide<true>(lox, loy, loz, hix, hiy, hiz, r);  // rare: a zero or tiny quotient
+    const float x0 = div_refine(px0, nx0, r.d.x, r.y.x), x1 = div_refine(px1, nx1, r.d.x, r.y.x);
+    const float y0 = div_refine(py0, ny0, r.d.y, r.y.y), y1 = div_refine(py1, ny1, r.d.y, r.y.y);
+    const float z0 = div_refine(pz0, nz0, r.d.z, r.y.z), z1 = div_refine(pz1, nz1, r.d.z, r.y.z);
     const float tn = fmaxf(fminf(x0, x1), fminf(y0, y1)), tf = fminf(fmaxf(x0, x1), fmaxf(y0, y1));
     const float zn = fminf(z0, z1), zf = fmaxf(z0, z1);
     b.overlap = (tn <= tf) && (tn <= zf) && (zn <= tf) && (tf > r.tmin);
@@ -194,8 +208,9 @@ PTD void load_tri(const DevScene& sc, uint32_t slot, V3& p0, V3& e1, V3& e2, int
 // reference's result at a fraction of the work.  With bound = +inf this is the plain reference traversal.
 template <bool SPECIAL, class C>
 PTD bool closest_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre, float bound, HitD& hit, uint32_t* lds_stack, C& wc) {
+    uint32_t spill[kSpillDepth];
     Stack st;
-    st.init(lds_stack);
+    st.init(lds_stack, spill);
     st.push(0u);
     float max_dis = fminf(ray.tmax, bound);
     bool found = false;
@@ -238,15 +253,16 @@ PTD bool closest_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre,
 // Closest hit in the reference's visit order.  Returns true when something was hit.
 template <class C>
 PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t* lds_stack, C& wc) {
-    const RayPre pre = make_pre(ray);
+    const RayPre pre = make_pre(sc, ray);
     if (pre.special) return closest_exact_t<true>(sc, ray, pre, __builtin_huge_valf(), hit, lds_stack, wc);
     return closest_exact_t<false>(sc, ray, pre, __builtin_huge_valf(), hit, lds_stack, wc);
 }
 
 template <bool SPECIAL, class C>
 PTD bool any_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre, int32_t& first_prim, uint32_t* lds_stack, C& wc) {
+    uint32_t spill[kSpillDepth];
     Stack st;
-    st.init(lds_stack);
+    st.init(lds_stack, spill);
     st.push(0u);
     first_prim = -1;
     while (!st.empty()) {
@@ -281,7 +297,7 @@ PTD bool any_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre, int
 // Any hit in the reference's visit order; first_prim receives the first accepted triangle or -1.
 template <class C>
 PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uint32_t* lds_stack, C& wc) {
-    const RayPre pre = make_pre(ray);
+    const RayPre pre = make_pre(sc, ray);
     if (pre.special) return any_exact_t<true>(sc, ray, pre, first_prim, lds_stack, wc);
     return any_exact_t<false>(sc, ray, pre, first_prim, lds_stack, wc);
 }
@@ -306,8 +322,9 @@ constexpr float kNearTie = 1.0f / 8192.0f;
 // reference reaches and keeps G as well.  Otherwise `redo` is set and the caller repeats the query in reference order.
 template <bool SPECIAL, class C>
 PTD bool closest_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, HitD& hit, bool& redo, uint32_t* lds_stack, C& wc) {
+    uint32_t spill[kSpillDepth];
     Stack st;
-    st.init(lds_stack);
+    st.init(lds_stack, spill);
     float best = ray.tmax;    // distance bound as the reference would hold it once the winner is found
     float window = ray.tmax;  // candidates up to here are still looked at
     bool near_tie = false;
@@ -379,7 +396,7 @@ PTD bool closest_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pr
 // behind the winner the ordered pass found.
 template <class C>
 PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& redo, uint32_t* lds_stack, C& wc) {
-    const RayPre pre = make_pre(ray);
+    const RayPre pre = make_pre(sc, ray);
     bool found;
     if (pre.special)
         found = closest_ordered_t<true>(sc, ray, pre, hit, redo, lds_stack, wc);
@@ -400,8 +417,9 @@ PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& redo
 // exactly what the reference returns, whatever the order.
 template <bool SPECIAL, class C>
 PTD bool any_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, uint32_t* lds_stack, C& wc) {
+    uint32_t spill[kSpillDepth];
     Stack st;
-    st.init(lds_stack);
+    st.init(lds_stack, spill);
     uint32_t cur = sc.wide_root;
     for (;;) {
         if (cur & kLeafBit) {
@@ -449,17 +467,18 @@ PTD bool any_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, u
 
 template <class C>
 PTD bool any_fast(const DevScene& sc, const RayD& ray, uint32_t* lds_stack, C& wc) {
-    const RayPre pre = make_pre(ray);
+    const RayPre pre = make_pre(sc, ray);
     if (pre.special) return any_ordered_t<true>(sc, ray, pre, lds_stack, wc);
     return any_ordered_t<false>(sc, ray, pre, lds_stack, wc);
 }
 
 // ------------------------------------------------------------------------------------------------ self test
 
-// 1 when div5 differs from the division instruction sequence for this operand pair (expected: never).
+// 1 when div_refine differs from the division instruction sequence for this operand pair (expected: never).
 PTD uint32_t div5_mismatch(float n, float d) {
-    if (!(fabsf(d) > 1e-18f && fabsf(d) < 1e18f) || !(fabsf(n) < 1e18f)) return 0u;
-    const float a = div5(n, d, 1.0f / d), b = n / d;
+    if (!(fabsf(d) > kDirLo && fabsf(d) < kDirHi) || !(fabsf(n) < 2.0f * kCoordHi) || !(fabsf(n * (1.0f / d)) >= kTinyQ)) return 0u;
+    const float y = 1.0f / d;
+    const float a = div_refine(n * y, n, d, y), b = n / d;
     return (as_u(a) != as_u(b) && !(a == 0.0f && b == 0.0f)) ? 1u : 0u;
 }
 

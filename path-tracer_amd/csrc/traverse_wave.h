@@ -1,0 +1,304 @@
+// Ordered traversal restructured for wave64 occupancy: a lane's query is advanced one node at a time by a loop that
+// the whole wave shares, so that
+//   - box steps and triangle steps run in separate phases (all lanes of a phase execute the same code), and
+//   - lanes whose query has ended take the next ray from the queue as soon as too few lanes are left busy, instead of
+//     idling until the slowest lane of the wave is done.
+// The per-node work is exactly that of closest_ordered_t / any_ordered_t (traverse.h): same box decisions, same
+// candidate set, same near-tie detection.  Rays that need the plain-division slab test ("special") and queries whose
+// result could depend on the visit order are not handled here; they are handed back to the caller (`defer`), which
+// runs them through closest_fast / closest_exact_t / any_fast in a follow-up kernel.
+#pragma once
+
+#include "traverse.h"
+
+namespace ptd {
+
+constexpr uint32_t kDone = kLeafBit;     // a leaf reference without triangles: nothing left to visit
+// Measured on a 1.6 M triangle interior scene: flat optimum around these values (refill 16..48, box lanes 24..40).
+constexpr uint32_t kRefillBelow = 32;    // fetch new rays once fewer lanes than this are busy
+constexpr uint32_t kMinBoxLanes = 28;    // leave the box phase for the triangle phase once fewer lanes than this have a box step to do
+
+PTD uint32_t lane_id() { return __lane_id(); }
+
+// Wave-level queue allocation: one atomic per wave, ballot + prefix popcount for the lane offset.
+PTD uint32_t wave_alloc(bool want, uint32_t* counter) {
+    const uint64_t mask = __ballot(want);
+    const uint32_t total = uint32_t(__popcll(mask));
+    uint32_t base = 0;
+    if (total != 0u) {
+        const int leader = __ffsll((unsigned long long)mask) - 1;
+        if (int(lane_id()) == leader) base = atomicAdd(counter, total);
+        base = uint32_t(__shfl(int(base), leader));
+    }
+    return base + uint32_t(__popcll(mask & ((1ull << lane_id()) - 1ull)));
+}
+
+struct ClosestLane {
+    RayPre pre;
+    float tmax;
+    float best, window;
+    bool near_tie;
+    HitD hit;
+    uint32_t cur;
+
+    PTD void begin(const DevScene& sc, const RayD& ray, const RayPre& p) {
+        pre = p;
+        tmax = ray.tmax;
+        best = window = ray.tmax;
+        near_tie = false;
+        hit = HitD{-1, 0.0f, 0.0f, 0.0f};
+        cur = sc.wide_root;
+    }
+    PTD void next(Stack& st) { cur = st.empty() ? kDone : st.pop(); }
+
+    // one 2-wide node: both boxes are evaluated without branching, leaf children are taken unconditionally
+    template <class C>
+    PTD void inner(const DevScene& sc, Stack& st, C& wc) {
+        const float4* w = sc.wide + 4 * size_t(cur);
+        wc.node();
+        const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
+        const BoxT b0 = box_decide<false>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
+        const BoxT b1 = box_decide<false>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
+        const bool l0 = (r0 & kLeafBit) != 0u, l1 = (r1 & kLeafBit) != 0u;
+        const bool go0 = l0 || (b0.overlap && b0.order <= window), go1 = l1 || (b1.overlap && b1.order <= window);
+        const float o0 = l0 ? -__builtin_huge_valf() : b0.order, o1 = l1 ? -__builtin_huge_valf() : b1.order;
+        if (go0 && go1) {
+            const bool swap = o1 < o0;
+            cur = swap ? r1 : r0;
+            st.push(swap ? r0 : r1);
+        } else if (go0 || go1) {
+            cur = go0 ? r0 : r1;
+        } else {
+            next(st);
+        }
+    }
+
+    template <class C>
+    PTD void leaf(const DevScene& sc, Stack& st, C& wc) {
+        const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
+        for (uint32_t k = 0; k < count; ++k) {
+            V3 p0, e1, e2;
+            int32_t prim;
+            load_tri(sc, first + k, p0, e1, e2, prim);
+            wc.tri();
+            float t, u, v;
+            if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, window, t, u, v)) {
+                near_tie = !(hit.prim < 0 || t * (1.0f + kNearTie) < best);
+                if (hit.prim < 0 || t <= best) {
+                    best = t;
+                    hit.prim = prim;
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    window = fminf(best * (1.0f + kNearTie), tmax);
+                }
+            }
+        }
+        next(st);
+    }
+
+    PTD bool redo() const { return near_tie || (hit.prim >= 0 && tmax < __builtin_huge_valf() && !(best * (1.0f + kNearTie) < tmax)); }
+    PTD float redo_bound() const { return hit.t * (1.0f + 2.0f * kNearTie); }
+};
+
+struct AnyLane {
+    RayPre pre;
+    float tmax;
+    bool occluded;
+    uint32_t cur;
+
+    PTD void begin(const DevScene& sc, const RayD& ray, const RayPre& p) {
+        pre = p;
+        tmax = ray.tmax;
+        occluded = false;
+        cur = sc.wide_root;
+    }
+    PTD void next(Stack& st) { cur = st.empty() ? kDone : st.pop(); }
+
+    template <class C>
+    PTD void inner(const DevScene& sc, Stack& st, C& wc) {
+        const float4* w = sc.wide + 4 * size_t(cur);
+        wc.node();
+        const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
+        const BoxT b0 = box_decide<false>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
+        const BoxT b1 = box_decide<false>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
+        const bool l0 = (r0 & kLeafBit) != 0u, l1 = (r1 & kLeafBit) != 0u;
+        const bool go0 = l0 || (b0.overlap && b0.tn < tmax), go1 = l1 || (b1.overlap && b1.tn < tmax);
+        if (go0 && go1) {
+            const bool swap = l1 && !l0;
+            cur = swap ? r1 : r0;
+            st.push(swap ? r0 : r1);
+        } else if (go0 || go1) {
+            cur = go0 ? r0 : r1;
+        } else {
+            next(st);
+        }
+    }
+
+    template <class C>
+    PTD void leaf(const DevScene& sc, Stack& st, C& wc) {
+        const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
+        for (uint32_t k = 0; k < count; ++k) {
+            V3 p0, e1, e2;
+            int32_t prim;
+            load_tri(sc, first + k, p0, e1, e2, prim);
+            wc.tri();
+            float t, u, v;
+            if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, tmax, t, u, v)) {
+                occluded = true;
+                cur = kDone;
+                return;
+            }
+        }
+        next(st);
+    }
+};
+
+// lane states of the shared loop
+constexpr int kLaneEmpty = 0, kLaneBusy = 1, kLaneDone = 2;
+
+// Takes `want` lanes' next queue positions from the shard's fetch counter.  Returns the position (valid when < count) and
+// clears `more` once the counter has passed the end of the queue.
+PTD uint32_t wave_fetch(bool want, uint32_t* counter, uint32_t count, bool& more) {
+    const uint64_t mask = __ballot(want);
+    const uint32_t n = uint32_t(__popcll(mask));
+    uint32_t base = 0;
+    if (n != 0u) {
+        const int leader = __ffsll((unsigned long long)mask) - 1;
+        if (int(lane_id()) == leader) base = atomicAdd(counter, n);
+        base = uint32_t(__shfl(int(base), leader));
+        more = base + n < count;
+    }
+    return base + uint32_t(__popcll(mask & ((1ull << lane_id()) - 1ull)));
+}
+
+// Closest hit for the rays of one shard.  Io supplies
+//   uint32_t count(shard)                                   rays in the shard's queue
+//   void load(shard, j, RayD&, Carry&)                      ray j and whatever the caller wants back at commit time
+//   void commit(shard, fin, j, hit, defer, bound, carry)    called by the whole wave; fin marks lanes with a result
+template <class Io, class C>
+PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, C& wc) {
+    const uint32_t count = io.count(shard);
+    uint32_t spill[kSpillDepth];
+    Stack st;
+    st.init(lds_stack, spill);
+    ClosestLane L;
+    L.cur = kDone;
+    L.hit = HitD{-1, 0.0f, 0.0f, 0.0f};
+    typename Io::Carry carry{};
+    uint32_t j = 0;
+    int state = kLaneEmpty;
+    bool defer = false, more = true;
+    float bound = 0.0f;
+    for (;;) {
+        if (__any(state == kLaneDone)) {
+            io.commit(shard, state == kLaneDone, j, L.hit, defer, bound, carry);
+            if (state == kLaneDone) state = kLaneEmpty;
+        }
+        if (more) {
+            const bool want = state == kLaneEmpty;
+            const uint32_t jj = wave_fetch(want, fetch + shard, count, more);
+            if (want && jj < count) {
+                j = jj;
+                RayD ray;
+                io.load(shard, j, ray, carry);
+                const RayPre pre = make_pre(sc, ray);
+                if (pre.special) {
+                    state = kLaneDone;
+                    defer = true;
+                    bound = __builtin_huge_valf();
+                    L.hit.prim = -1;
+                } else {
+                    L.begin(sc, ray, pre);
+                    st.sp = 0;
+                    state = kLaneBusy;
+                    defer = false;
+                }
+            }
+        }
+        if (!__any(state == kLaneBusy)) {
+            if (more || __any(state == kLaneDone)) continue;
+            break;
+        }
+        const uint32_t low = more ? kRefillBelow : 1u;
+        for (;;) {
+            for (;;) {
+                const bool inner = state == kLaneBusy && !(L.cur >> 31);
+                const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
+                if (n_inner == 0u) break;
+                if (inner) L.inner(sc, st, wc);
+                if (n_inner < kMinBoxLanes) break;
+            }
+            if (state == kLaneBusy && L.cur > kDone) L.leaf(sc, st, wc);
+            if (state == kLaneBusy && L.cur == kDone) {
+                state = kLaneDone;
+                defer = L.redo();
+                bound = L.redo_bound();
+            }
+            if (uint32_t(__popcll(__ballot(state == kLaneBusy))) < low) break;
+        }
+    }
+}
+
+// Any hit for the rays of one shard.  Io: count(shard), load(shard, j, RayD&, Carry&),
+// commit(shard, fin, j, occluded, defer, carry) -- per lane, no wave-level operation required.
+template <class Io, class C>
+PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, C& wc) {
+    const uint32_t count = io.count(shard);
+    uint32_t spill[kSpillDepth];
+    Stack st;
+    st.init(lds_stack, spill);
+    AnyLane L;
+    L.cur = kDone;
+    L.occluded = false;
+    typename Io::Carry carry{};
+    uint32_t j = 0;
+    int state = kLaneEmpty;
+    bool defer = false, more = true;
+    for (;;) {
+        if (__any(state == kLaneDone)) {
+            io.commit(shard, state == kLaneDone, j, L.occluded, defer, carry);
+            if (state == kLaneDone) state = kLaneEmpty;
+        }
+        if (more) {
+            const bool want = state == kLaneEmpty;
+            const uint32_t jj = wave_fetch(want, fetch + shard, count, more);
+            if (want && jj < count) {
+                j = jj;
+                RayD ray;
+                io.load(shard, j, ray, carry);
+                const RayPre pre = make_pre(sc, ray);
+                if (pre.special) {
+                    state = kLaneDone;
+                    defer = true;
+                } else {
+                    L.begin(sc, ray, pre);
+                    st.sp = 0;
+                    state = kLaneBusy;
+                    defer = false;
+                }
+            }
+        }
+        if (!__any(state == kLaneBusy)) {
+            if (more || __any(state == kLaneDone)) continue;
+            break;
+        }
+        const uint32_t low = more ? kRefillBelow : 1u;
+        for (;;) {
+            for (;;) {
+                const bool inner = state == kLaneBusy && !(L.cur >> 31);
+                const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
+                if (n_inner == 0u) break;
+                if (inner) L.inner(sc, st, wc);
+                if (n_inner < kMinBoxLanes) break;
+            }
+            if (state == kLaneBusy && L.cur > kDone) L.leaf(sc, st, wc);
+            if (state == kLaneBusy && L.cur == kDone) state = kLaneDone;
+            if (uint32_t(__popcll(__ballot(state == kLaneBusy))) < low) break;
+        }
+    }
+}
+
+}  // namespace ptd

@@ -3,7 +3,7 @@ sys.path[:0]=['path-tracer_amd/python','oracle','tests']
 import numpy as np
 from pt_hip import api, synth
 import orc, helpers
-t=time.time(); sd=synth.library_synth(); print('gen',time.time()-t,'tris',sd.n_tris, flush=True)
+t=time.time(); sd=synth.library_synth(detail=int(sys.argv[1]) if len(sys.argv)>1 else 4); print('gen',time.time()-t,'tris',sd.n_tris, flush=True)
 t=time.time(); g=api.Scene(sd); print('gpu scene',time.time()-t,'depth',g.host.depth,'nodes',len(g.host.nodes), flush=True)
 t=time.time(); o=orc.Scene(sd); print('oracle scene',time.time()-t, flush=True)
 for mode in (0,1):
