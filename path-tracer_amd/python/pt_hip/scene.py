@@ -57,6 +57,44 @@ class SceneData:
             return np.zeros(0, np.uint32), np.zeros((0, 3), np.float32)
         return np.concatenate(tri), np.concatenate(lemit).astype(np.float32)
 
+    def export_dir(self, root, name=None):
+        """Write <root>/<name>/<name>.{obj,mtl,xml} in the subset of the formats the reference reads (src/scene.cpp:23-177),
+        with float32-exact number formatting.  Textures are not exported."""
+        name = name or self.name
+        folder = os.path.join(root, name)
+        os.makedirs(folder, exist_ok=True)
+        f9 = lambda v: " ".join(repr(float(np.float32(x))) for x in v)
+        with open(os.path.join(folder, name + ".mtl"), "w") as f:
+            for i, n in enumerate(self.mat_names):
+                f.write("newmtl %s\nKd %s\nKs %s\nNs %s\n" % (n, f9(self.mat_kd[i]), f9(self.mat_ks[i]), f9([self.mat_ns[i]])))
+        with open(os.path.join(folder, name + ".obj"), "w") as f:
+            f.write("mtllib %s.mtl\n" % name)
+            for v in self.verts:
+                f.write("v %s\n" % f9(v))
+            for v in self.normals:
+                f.write("vn %s\n" % f9(v))
+            for v in self.uvs:
+                f.write("vt %s\n" % f9(v))
+            cur = -1
+            for t in range(self.n_tris):
+                if int(self.mat_id[t]) != cur:
+                    cur = int(self.mat_id[t])
+                    f.write("usemtl %s\n" % self.mat_names[cur])
+                c = []
+                for k in range(3):
+                    v, n, u = int(self.vi[t, k]), int(self.ni[t, k]), int(self.ti[t, k])
+                    c.append("%d" % v if not (n or u) else "%d/%s/%s" % (v, u or "", n or "") if n else "%d/%d" % (v, u))
+                f.write("f %s\n" % " ".join(c))
+        with open(os.path.join(folder, name + ".xml"), "w") as f:
+            f.write('<?xml version="1.0" encoding="utf-8"?>\n<camera type="perspective" width="%d" height="%d" fovy="%s">\n'
+                    % (self.width, self.height, f9([self.fovy])))
+            for tag, v in (("eye", self.eye), ("lookat", self.lookat), ("up", self.up)):
+                f.write('\t<%s x="%s" y="%s" z="%s"/>\n' % ((tag,) + tuple(f9([c]) for c in v)))
+            f.write("</camera>\n")
+            for n, rad in self.light_infos:
+                f.write('<light mtlname="%s" radiance="%s"/>\n' % (n, ",".join(f9([c]) for c in rad)))
+        return folder
+
     def save(self, path):
         if self.textures:
             raise ValueError("textured scenes are not stored as npz fixtures")

@@ -189,3 +189,34 @@ def test_hip_library_reports_errors_without_a_gpu_or_init():
     h = C.c_void_p()
     rc = lib.pt_hip_scene_create(None, C.byref(h))
     assert rc < 0 and lib.pt_hip_last_error()
+
+
+def test_export_round_trip_through_both_loaders(tmp_path):
+    """SceneData.export_dir writes float32-exact OBJ/MTL/XML: the C++ loader must reproduce the arrays, BVH and camera."""
+    from pt_hip import synth
+    for sd in (synth.cornell_box(96, 96), synth.library_synth(detail=1, width=64, height=48)):
+        folder = sd.export_dir(str(tmp_path), "cornell-box")
+        h, desc = _load_with_host(folder, "cornell-box")
+        _check_against_python_loader(desc, sd)
+        for i in range(desc.n_mats):
+            assert list(desc.mats[i].kd) == list(sd.mat_kd[i]) and list(desc.mats[i].ks) == list(sd.mat_ks[i]) and desc.mats[i].ns == sd.mat_ns[i]
+        api.host_lib().pt_host_scene_free(h)
+
+
+CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "path-tracer_amd", "bin", "PathTracer")
+
+
+def test_cli_argument_errors_match_the_reference(tmp_path):
+    """src/main.cpp:110-154: unknown tokens and bad counts print a message and return -1; load errors return 1."""
+    import subprocess
+    assert os.path.exists(CLI), "build the front end first (make -C path-tracer_amd cli)"
+    r = subprocess.run([CLI, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 255 and "Unknown argument: --bogus" in r.stderr
+    r = subprocess.run([CLI, "--spp", "0"], capture_output=True, text=True)
+    assert r.returncode == 255 and '"--spp" argument expects a positive integer' in r.stderr
+    r = subprocess.run([CLI, "-t"], capture_output=True, text=True)
+    assert r.returncode == 255 and '"--threads" argument expects a positive integer' in r.stderr
+    r = subprocess.run([CLI, "--bdpt"], capture_output=True, text=True)
+    assert r.returncode == 255
+    r = subprocess.run([CLI, "--no-gui", "--scenes", str(tmp_path), "library"], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.startswith("Error: ")
