@@ -54,7 +54,43 @@ struct DeferQ {
     uint32_t* count;  // [shard]
 };
 
-constexpr uint32_t kWaveBlocks = 8;  // workgroups per shard of a wave-refill kernel: 16 waves share a shard's queue
+// Per-shard counters a kernel clears for a LATER kernel of the same stream (none of them is used by the kernel that
+// clears them): saves the separate fill launches between the kernels of a bounce.
+struct ZeroList {
+    uint32_t* p[5];
+};
+PTD void zero_counters(const ZeroList& z, uint32_t shard) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (z.p[i]) z.p[i][shard] = 0u;
+    }
+}
+
+// Hand-off of deferred-ray records between the workgroups of a shard, which may sit on different XCDs (separate L2s).
+// A device-scope fence would write back and invalidate the whole L2 -- and with it the BVH working set -- at every
+// workgroup end (measured: traversal kernels 1.6x slower).  Instead the few words that cross workgroups are written
+// and read with device-scope atomic accesses, which go to the coherent level themselves; the writer only waits for
+// its own stores to complete before the workgroup signs off.
+PTD void store_shared(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PTD uint32_t load_fresh(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// True in every thread of the block that is the last of its shard (gridDim.x blocks per shard) to get here.
+PTD bool last_block_of_shard(uint32_t* done, uint32_t shard) {
+    __shared__ uint32_t s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have completed
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(done + shard, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    return s_last != 0u;
+}
+
+#ifndef WPE
+#define WPE 6
+#endif
+constexpr uint32_t kWaveBlocks = 8;   // workgroups per shard of the traversal kernels
+constexpr uint32_t kShadeBlocks = 8;  // workgroups per shard of k_shade (256 threads each)
+constexpr uint32_t kExactBlocks = 16; // workgroups per shard of the reference-order traversal kernels  // workgroups per shard of a wave-refill kernel: 16 waves share a shard's queue
 
 struct PassArgs {
     const uint32_t* frame_tab;  // [frame_local][1024] Sobol' words of the sample numbers of this pass
@@ -224,34 +260,37 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
 // Scene::rayIntersect for rays spawned by Intersection::genRay (src/shape.cpp:186-189): tmin 0, tmax +inf.
 // Hits are appended to the shard's hit list; a miss ends the path (src/integrator.cpp:53) and is simply not listed.
 template <class C>
-__global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathQ q, HitQ hq, int traversal, uint32_t* misc) {
+__global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathQ q, HitQ hq, int traversal, ZeroList zl, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t shard = blockIdx.y;
-    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-    const size_t i = size_t(shard) * kShard + j;
+    zero_counters(zl, shard);
+    const size_t sbase = size_t(shard) * kShard;
+    const uint32_t n = q.count[shard];
     C wc;
-    bool found = false;
-    HitD h{-1, 0.0f, 0.0f, 0.0f};
-    float4 c{};
-    if (j < q.count[shard]) {
-        const float4 a = q.a[i], b = q.b[i];
-        c = q.c[i];
-        const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
-        found = trace_closest(sc, traversal, ray, h, s_stack + threadIdx.x, misc, wc);
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const uint32_t j = base + threadIdx.x;
+        bool found = false;
+        HitD h{-1, 0.0f, 0.0f, 0.0f};
+        float4 c{};
+        if (j < n) {
+            const float4 a = q.a[sbase + j], b = q.b[sbase + j];
+            c = q.c[sbase + j];
+            const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
+            found = trace_closest(sc, traversal, ray, h, s_stack + threadIdx.x, misc, wc);
+        }
+        const uint32_t local = wave_alloc(found, hq.count + shard);
+        if (found) {
+            hq.h0[sbase + local] = make_float4(as_f(j), as_f(uint32_t(h.prim)), h.u, h.v);
+            hq.h1[sbase + local] = make_float4(c.z, c.w, h.t, 0.0f);
+        }
     }
     flush_counts(wc, misc, 1);
-    const uint32_t local = wave_alloc(found, hq.count + shard);
-    if (found) {
-        const size_t dst = size_t(shard) * kShard + local;
-        hq.h0[dst] = make_float4(as_f(j), as_f(uint32_t(h.prim)), h.u, h.v);
-        hq.h1[dst] = make_float4(c.z, c.w, h.t, 0.0f);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ wave-refill variants
 
 // Ordered-mode extend: same inputs and outputs as k_extend, rays taken from the shard's queue through a fetch counter
-// (closest_wave).  Hits go to the hit list; deferred rays go to `dq` and are finished by k_extend_deferred.
+// (closest_wave).  Hits go to the hit list; deferred rays go to `dq` and are finished by the shard's last workgroup.
 struct ExtendIo {
     PathQ q;
     HitQ hq;
@@ -278,45 +317,39 @@ struct ExtendIo {
         const bool d = fin && defer;
         if (__any(d)) {
             const uint32_t dl = wave_alloc(d, dq.count + shard);
-            if (d) dq.e[sbase + dl] = make_uint2(j, as_u(bound));
+            if (d) {
+                store_shared(&dq.e[sbase + dl].x, j);
+                store_shared(&dq.e[sbase + dl].y, as_u(bound));
+            }
         }
     }
 };
 
+// The deferred rays of one shard, by one workgroup: special rays through the generic ordered query, order-sensitive ones
+// in reference order up to their bound.
 template <class C>
-__global__ __launch_bounds__(kBlock) void k_extend_wave(DevScene sc, ExtendIo io, uint32_t* fetch, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
-    C wc;
-    closest_wave(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
-    flush_counts(wc, misc, 1);
-}
-
-template <class C>
-__global__ __launch_bounds__(kBlock) void k_extend_deferred(DevScene sc, PathQ q, HitQ hq, DeferQ dq, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
-    const uint32_t shard = blockIdx.y;
+PTD void extend_deferred(const DevScene& sc, const PathQ& q, const HitQ& hq, const DeferQ& dq, uint32_t shard, uint32_t* lds_stack,
+                         uint32_t* misc, C& wc) {
     const size_t sbase = size_t(shard) * kShard;
-    const uint32_t n = dq.count[shard];
-    C wc;
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    const uint32_t n = load_fresh(dq.count + shard);
+    for (uint32_t base = 0; base < n; base += kBlock) {
         const uint32_t k = base + threadIdx.x;
         bool found = false;
         HitD h{-1, 0.0f, 0.0f, 0.0f};
         uint32_t j = 0;
         float4 c{};
         if (k < n) {
-            const uint2 e = dq.e[sbase + k];
-            j = e.x;
-            const float bound = as_f(e.y);
+            j = load_fresh(&dq.e[sbase + k].x);
+            const float bound = as_f(load_fresh(&dq.e[sbase + k].y));
             const float4 a = q.a[sbase + j], b = q.b[sbase + j];
             c = q.c[sbase + j];
             const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
             bool redo = true;
             if (bound == __builtin_huge_valf()) {
-                found = closest_fast(sc, ray, h, redo, s_stack + threadIdx.x, wc);
+                found = closest_fast(sc, ray, h, redo, lds_stack, wc);
             } else {
                 const RayPre pre = make_pre(sc, ray);
-                found = closest_exact_t<false>(sc, ray, pre, bound, h, s_stack + threadIdx.x, wc);
+                found = closest_exact_t<false>(sc, ray, pre, bound, h, lds_stack, wc);
             }
             if (redo && misc) atomicAdd(misc, 1u);
         }
@@ -326,6 +359,19 @@ __global__ __launch_bounds__(kBlock) void k_extend_deferred(DevScene sc, PathQ q
             hq.h1[sbase + local] = make_float4(c.z, c.w, h.t, 0.0f);
         }
     }
+}
+
+// gridDim.x workgroups share a shard's queue; the last one to run dry also finishes the shard's deferred rays, so that
+// this (slow, nearly serial) work overlaps with the other shards instead of forming a tail of its own.
+template <class C>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_extend_wave(DevScene sc, ExtendIo io, uint32_t* fetch,
+                                                                                                    uint32_t* done, ZeroList zl, uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t shard = blockIdx.y;
+    zero_counters(zl, shard);
+    C wc;
+    closest_wave(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
+    if (last_block_of_shard(done, shard)) extend_deferred(sc, io.q, io.hq, io.dq, shard, s_stack + threadIdx.x, misc, wc);
     flush_counts(wc, misc, 1);
 }
 
@@ -357,38 +403,34 @@ struct ShadowIo {
         const bool d = fin && defer;
         if (__any(d)) {
             const uint32_t dl = wave_alloc(d, dq.count + shard);
-            if (d) dq.e[sbase + dl] = make_uint2(j, 0u);
+            if (d) store_shared(&dq.e[sbase + dl].x, j);
         }
     }
 };
 
 template <class C>
-__global__ __launch_bounds__(kBlock) void k_shadow_wave(DevScene sc, ShadowIo io, uint32_t* fetch, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
-    C wc;
-    any_wave(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
-    flush_counts(wc, misc, 2);
-}
-
-template <class C>
-__global__ __launch_bounds__(kBlock) void k_shadow_deferred(DevScene sc, ShadowQ sh, DeferQ dq, float4* lbuf, uint32_t* misc) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_shadow_wave(DevScene sc, ShadowIo io, uint32_t* fetch,
+                                                                                                    uint32_t* done, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t shard = blockIdx.y;
-    const size_t sbase = size_t(shard) * kShard;
-    const uint32_t n = dq.count[shard];
     C wc;
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
-        const uint32_t j = dq.e[sbase + k].x;
-        const float4 a = sh.a[sbase + j], b = sh.b[sbase + j];
-        const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
-        if (!any_fast(sc, ray, s_stack + threadIdx.x, wc)) {
-            const float4 v = sh.c[sbase + j];
-            const uint32_t slot = as_u(b.w);
-            float4 L = lbuf[slot];
-            L.x += v.x;
-            L.y += v.y;
-            L.z += v.z;
-            lbuf[slot] = L;
+    any_wave(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
+    if (last_block_of_shard(done, shard)) {  // plain-division rays of the shard
+        const size_t sbase = size_t(shard) * kShard;
+        const uint32_t n = load_fresh(io.dq.count + shard);
+        for (uint32_t k = threadIdx.x; k < n; k += kBlock) {
+            const uint32_t j = load_fresh(&io.dq.e[sbase + k].x);
+            const float4 a = io.sh.a[sbase + j], b = io.sh.b[sbase + j];
+            const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
+            if (!any_fast(sc, ray, s_stack + threadIdx.x, wc)) {
+                const float4 v = io.sh.c[sbase + j];
+                const uint32_t slot = as_u(b.w);
+                float4 L = io.lbuf[slot];
+                L.x += v.x;
+                L.y += v.y;
+                L.z += v.z;
+                io.lbuf[slot] = L;
+            }
         }
     }
     flush_counts(wc, misc, 2);
@@ -502,135 +544,139 @@ __global__ __launch_bounds__(kBlock) void k_occluded_fix(DevScene sc, const floa
 // Memory reads are arranged in three dependent levels: (1) the hit-list entry; (2) the path state, the triangle's
 // shading record and the Sobol' window (all addressed from the entry); (3) the record of the light chosen by the first
 // Sobol' value.
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq, PathQ in, PathQ out, ShadowQ sh, float4* lbuf) {
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq, PathQ in, PathQ out, ShadowQ sh, float4* lbuf, ZeroList zl) {
     const uint32_t shard = blockIdx.y;
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    zero_counters(zl, shard);
     const size_t sbase = size_t(shard) * kShard;
-    bool cont = false, want_shadow = false;
-    float4 na{}, nb{}, nc{}, sa{}, sb{}, sc4{};
-    uint32_t slot = 0;
-    if (j < hq.count[shard]) {
-        const float4 h0 = hq.h0[sbase + j], h1 = hq.h1[sbase + j];
-        const size_t pi = sbase + as_u(h0.x);
-        const uint32_t prim = as_u(h0.y);
-        const uint32_t pix = as_u(h1.x), meta = as_u(h1.y);
-        const uint32_t frame = meta >> 16;
-        int bounce = int((meta >> 10) & 63u);
-        // level 2 reads
-        const float4 a = in.a[pi], b = in.b[pi], c = in.c[pi];
-        slot = in.slot[pi];
-        TriRec tr;
-        tr.load(sc, prim);
-        Sampler smp;
-        smp.start(sc, pa.frame_tab + size_t(frame) * 1024u, pix & 0xffffu, pix >> 16, int(meta & 1023u));
-        // level 3: the light record depends on the first Sobol' value only
-        LightRec lr;
-        float u1 = 0.0f;
-        if (sc.n_lights != 0u) {
-            u1 = smp.s1();
-            uint32_t li = uint32_t(int(u1 * float(sc.n_lights)));  // include/pt/light.h:58-60
-            if (li >= sc.n_lights) li = sc.n_lights - 1u;          // the reference would throw here; clamp instead
-            lr.load(sc, li);
-        }
+    const uint32_t n = hq.count[shard];
+    for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+        const uint32_t j = base + threadIdx.x;
+        bool cont = false, want_shadow = false;
+        float4 na{}, nb{}, nc{}, sa{}, sb{}, sc4{};
+        uint32_t slot = 0;
+        if (j < n) {
+            const float4 h0 = hq.h0[sbase + j], h1 = hq.h1[sbase + j];
+            const size_t pi = sbase + as_u(h0.x);
+            const uint32_t prim = as_u(h0.y);
+            const uint32_t pix = as_u(h1.x), meta = as_u(h1.y);
+            const uint32_t frame = meta >> 16;
+            int bounce = int((meta >> 10) & 63u);
+            // level 2 reads
+            const float4 a = in.a[pi], b = in.b[pi], c = in.c[pi];
+            slot = in.slot[pi];
+            TriRec tr;
+            tr.load(sc, prim);
+            Sampler smp;
+            smp.start(sc, pa.frame_tab + size_t(frame) * 1024u, pix & 0xffffu, pix >> 16, int(meta & 1023u));
+            // level 3: the light record depends on the first Sobol' value only
+            LightRec lr;
+            float u1 = 0.0f;
+            if (sc.n_lights != 0u) {
+                u1 = smp.s1();
+                uint32_t li = uint32_t(int(u1 * float(sc.n_lights)));  // include/pt/light.h:58-60
+                if (li >= sc.n_lights) li = sc.n_lights - 1u;          // the reference would throw here; clamp instead
+                lr.load(sc, li);
+            }
 
-        const V3 ro{a.x, a.y, a.z}, rd{a.w, b.x, b.y};
-        V3 T{b.z, b.w, c.x};
-        const float brdfPdf = c.y;
-        Surf it;
-        complete(tr, h0.z, h0.w, it);
-        const V3 wo = -rd;
-        const Mat m = surface_material(sc, tr, prim, h0.z, h0.w);
+            const V3 ro{a.x, a.y, a.z}, rd{a.w, b.x, b.y};
+            V3 T{b.z, b.w, c.x};
+            const float brdfPdf = c.y;
+            Surf it;
+            complete(tr, h0.z, h0.w, it);
+            const V3 wo = -rd;
+            const Mat m = surface_material(sc, tr, prim, h0.z, h0.w);
 
-        // emitted radiance with MIS against light sampling (src/integrator.cpp:58-69)
-        if (tr.light_id() >= 0) {
-            const V3 Le = dot(it.n, wo) > 0.0f ? tr.lemit() : mk3(0.0f);
-            V3 add;
-            if (bounce == 0) {
-                add = cmul(T, Le);
+            // emitted radiance with MIS against light sampling (src/integrator.cpp:58-69)
+            if (tr.light_id() >= 0) {
+                const V3 Le = dot(it.n, wo) > 0.0f ? tr.lemit() : mk3(0.0f);
+                V3 add;
+                if (bounce == 0) {
+                    add = cmul(T, Le);
+                } else {
+                    float lpdf = light_pdf(tr.inv_area(), it.p, it.n, ro, rd);
+                    lpdf *= 1.0f / float(sc.n_lights);
+                    const float w = power_heuristic(brdfPdf, lpdf);
+                    add = w * cmul(T, Le);
+                }
+                float4 L = lbuf[slot];
+                L.x += add.x;
+                L.y += add.y;
+                L.z += add.z;
+                lbuf[slot] = L;
+            }
+
+            // light sampling (src/integrator.cpp:109-141)
+            if (sc.n_lights != 0u) {
+                const float selectPdf = 1.0f / float(sc.n_lights);
+                const LiSample ls = light_sample(lr, it.p, it.n, smp.s2());
+                if (ls.pdfDir != 0.0f) {
+                    // Scene::unocculded (src/scene.cpp:213-220)
+                    const V3 p0 = it.p + it.n * kEps, p1 = ls.p + ls.n * kEps;
+                    const V3 d = p1 - p0;
+                    const float dist = norm(d);
+                    const V3 sd = d / dist;
+                    V3 f;
+                    float bp;
+                    brdf_eval_pdf(m, it.n, wo, ls.wi, f, bp);
+                    const float cosTheta = dot(it.n, ls.wi);
+                    const float lp = ls.pdfDir * selectPdf;
+                    const float w = power_heuristic(lp, bp);
+                    const V3 Ld = w * cmul(f, ls.L) * cosTheta / lp;
+                    const V3 contrib = cmul(T, Ld);
+                    want_shadow = true;
+                    sa = make_float4(p0.x, p0.y, p0.z, sd.x);
+                    sb = make_float4(sd.y, sd.z, dist * (1 - kEps), as_f(slot));
+                    sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+                }
+            }
+
+            // BRDF sampling; the 2-D sample is drawn before the 1-D one (src/integrator.cpp:83, right-to-left arguments)
+            const V2 u = smp.s2();
+            const float uc = smp.s1();
+            const BSample bs = brdf_sample(m, it, wo, uc, u);
+            float newPdf = brdfPdf;
+            bool go = true;
+            if (bs.specular) {
+                bounce--;
+                newPdf = 1.0f;
             } else {
-                float lpdf = light_pdf(tr.inv_area(), it.p, it.n, ro, rd);
-                lpdf *= 1.0f / float(sc.n_lights);
-                const float w = power_heuristic(brdfPdf, lpdf);
-                add = w * cmul(T, Le);
+                if (sqnorm(bs.f) == 0.0f || bs.pdf == 0.0f) go = false;
+                if (go) {
+                    const V3 thr = bs.f * dot(it.n, bs.wi) / bs.pdf;
+                    T = cmul(T, thr);
+                    newPdf = bs.pdf;
+                }
             }
-            float4 L = lbuf[slot];
-            L.x += add.x;
-            L.y += add.y;
-            L.z += add.z;
-            lbuf[slot] = L;
-        }
-
-        // light sampling (src/integrator.cpp:109-141)
-        if (sc.n_lights != 0u) {
-            const float selectPdf = 1.0f / float(sc.n_lights);
-            const LiSample ls = light_sample(lr, it.p, it.n, smp.s2());
-            if (ls.pdfDir != 0.0f) {
-                // Scene::unocculded (src/scene.cpp:213-220)
-                const V3 p0 = it.p + it.n * kEps, p1 = ls.p + ls.n * kEps;
-                const V3 d = p1 - p0;
-                const float dist = norm(d);
-                const V3 sd = d / dist;
-                V3 f;
-                float bp;
-                brdf_eval_pdf(m, it.n, wo, ls.wi, f, bp);
-                const float cosTheta = dot(it.n, ls.wi);
-                const float lp = ls.pdfDir * selectPdf;
-                const float w = power_heuristic(lp, bp);
-                const V3 Ld = w * cmul(f, ls.L) * cosTheta / lp;
-                const V3 contrib = cmul(T, Ld);
-                want_shadow = true;
-                sa = make_float4(p0.x, p0.y, p0.z, sd.x);
-                sb = make_float4(sd.y, sd.z, dist * (1 - kEps), as_f(slot));
-                sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
-            }
-        }
-
-        // BRDF sampling; the 2-D sample is drawn before the 1-D one (src/integrator.cpp:83, right-to-left arguments)
-        const V2 u = smp.s2();
-        const float uc = smp.s1();
-        const BSample bs = brdf_sample(m, it, wo, uc, u);
-        float newPdf = brdfPdf;
-        bool go = true;
-        if (bs.specular) {
-            bounce--;
-            newPdf = 1.0f;
-        } else {
-            if (sqnorm(bs.f) == 0.0f || bs.pdf == 0.0f) go = false;
             if (go) {
-                const V3 thr = bs.f * dot(it.n, bs.wi) / bs.pdf;
-                T = cmul(T, thr);
-                newPdf = bs.pdf;
+                const V3 no = it.p + it.ng * kEps;  // Intersection::genRay (src/shape.cpp:186-189)
+                // Russian roulette (src/integrator.cpp:99-103)
+                if (maxc(T) < 1.0f && bounce > 1) {
+                    const float qq = std_max(0.0f, 1.0f - maxc(T));
+                    if (smp.s1() < qq) go = false;
+                    T = T / (1.0f - qq);
+                }
+                bounce++;
+                if (go && bounce < int(pa.max_bounce)) {
+                    cont = true;
+                    na = make_float4(no.x, no.y, no.z, bs.wi.x);
+                    nb = make_float4(bs.wi.y, bs.wi.z, T.x, T.y);
+                    nc = make_float4(T.z, newPdf, as_f(pix), as_f(uint32_t(smp.dim) | (uint32_t(bounce) << 10) | (frame << 16)));
+                }
             }
         }
-        if (go) {
-            const V3 no = it.p + it.ng * kEps;  // Intersection::genRay (src/shape.cpp:186-189)
-            // Russian roulette (src/integrator.cpp:99-103)
-            if (maxc(T) < 1.0f && bounce > 1) {
-                const float qq = std_max(0.0f, 1.0f - maxc(T));
-                if (smp.s1() < qq) go = false;
-                T = T / (1.0f - qq);
-            }
-            bounce++;
-            if (go && bounce < int(pa.max_bounce)) {
-                cont = true;
-                na = make_float4(no.x, no.y, no.z, bs.wi.x);
-                nb = make_float4(bs.wi.y, bs.wi.z, T.x, T.y);
-                nc = make_float4(T.z, newPdf, as_f(pix), as_f(uint32_t(smp.dim) | (uint32_t(bounce) << 10) | (frame << 16)));
-            }
+        const uint32_t sl = wave_alloc(want_shadow, sh.count + shard);
+        if (want_shadow) {
+            sh.a[sbase + sl] = sa;
+            sh.b[sbase + sl] = sb;
+            sh.c[sbase + sl] = sc4;
         }
-    }
-    const uint32_t sl = wave_alloc(want_shadow, sh.count + shard);
-    if (want_shadow) {
-        sh.a[sbase + sl] = sa;
-        sh.b[sbase + sl] = sb;
-        sh.c[sbase + sl] = sc4;
-    }
-    const uint32_t nl = wave_alloc(cont, out.count + shard);
-    if (cont) {
-        out.a[sbase + nl] = na;
-        out.b[sbase + nl] = nb;
-        out.c[sbase + nl] = nc;
-        out.slot[sbase + nl] = slot;
+        const uint32_t nl = wave_alloc(cont, out.count + shard);
+        if (cont) {
+            out.a[sbase + nl] = na;
+            out.b[sbase + nl] = nb;
+            out.c[sbase + nl] = nc;
+            out.slot[sbase + nl] = slot;
+        }
     }
 }
 
@@ -641,14 +687,14 @@ template <class C>
 __global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, ShadowQ sh, int traversal, float4* lbuf, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t shard = blockIdx.y;
-    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-    const size_t i = size_t(shard) * kShard + j;
+    const size_t sbase = size_t(shard) * kShard;
+    const uint32_t n = sh.count[shard];
     C wc;
-    if (j < sh.count[shard]) {
-        const float4 a = sh.a[i], b = sh.b[i];
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
+        const float4 a = sh.a[sbase + j], b = sh.b[sbase + j];
         const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
         if (!trace_any(sc, traversal, ray, s_stack + threadIdx.x, wc)) {
-            const float4 c = sh.c[i];
+            const float4 c = sh.c[sbase + j];
             const uint32_t slot = as_u(b.w);
             float4 L = lbuf[slot];
             L.x += c.x;

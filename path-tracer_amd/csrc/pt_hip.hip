@@ -70,25 +70,35 @@ inline uint64_t frame_index(uint32_t m, uint64_t frame) {
     return index;
 }
 
+constexpr int kRing = 4;  // counter snapshots in flight between the stream and the host
+
 struct Workspace {
     uint32_t cap_slots = 0;   // padded to whole shards
     uint32_t n_shards = 0;
     PathQ q[2]{};
-    HitQ hq{};
+    HitQ hq{};                // count points at hit_count[bounce & 1]
     ShadowQ sh{};
-    DeferQ dqe{}, dqs{};  // rays handed back by the wave-refill extend / shadow kernels
+    DeferQ dqe{}, dqs{};      // rays handed back by the wave-refill extend / shadow kernels
     float4* lbuf = nullptr;
-    // device counters, n_shards words each: [q0 | q1 | hit | shadow | fetch extend | fetch shadow | deferred extend |
-    // deferred shadow], then kMiscWords
+    // device counters, n_shards words each:
+    //   [q0 | q1 | hit0 | hit1 | shadow | fetch extend | fetch shadow | deferred extend | deferred shadow | done extend |
+    //    done shadow], then kMiscWords
+    uint32_t* counters = nullptr;
+    uint32_t* hit_count[2] = {nullptr, nullptr};
     uint32_t* fetch_e = nullptr;
     uint32_t* fetch_s = nullptr;
-    uint32_t* counters = nullptr;
-    uint32_t* h_counters = nullptr;  // pinned host mirror
+    uint32_t* done_e = nullptr;
+    uint32_t* done_s = nullptr;
     uint32_t* misc = nullptr;
+    uint32_t* h_counters = nullptr;  // pinned host mirror: kRing snapshots of the first 5 arrays, then kMiscWords
+    hipEvent_t ring_ev[kRing] = {};
     uint32_t* frame_tab = nullptr;
     size_t frame_cap = 0;  // in frames
     std::vector<void*> owned;
-    size_t counter_words() const { return size_t(8) * n_shards + kMiscWords; }
+    size_t misc_offset() const { return (size_t(11) * n_shards + 1) & ~size_t(1); }  // 64-bit atomics live in misc: keep it 8-byte aligned
+    size_t counter_words() const { return misc_offset() + kMiscWords; }
+    size_t snapshot_words() const { return size_t(5) * n_shards; }
+    uint32_t* h_misc() const { return h_counters + size_t(kRing) * snapshot_words(); }
 };
 
 struct EventPool {
@@ -369,6 +379,8 @@ void ws_release(Workspace& ws) {
     for (void* p : ws.owned) (void)hipFree(p);
     ws.owned.clear();
     if (ws.h_counters) (void)hipHostFree(ws.h_counters);
+    for (hipEvent_t e : ws.ring_ev)
+        if (e) (void)hipEventDestroy(e);
     ws = Workspace();
 }
 
@@ -395,21 +407,28 @@ int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
         if (int rc = ws_alloc(ws, &ws.lbuf, padded)) return rc;
         if (int rc = ws_alloc(ws, &ws.counters, ws.counter_words())) return rc;
         if (int rc = ws_alloc(ws, &ws.frame_tab, n_frames * 1024)) return rc;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ws.h_counters), ws.counter_words() * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ws.h_counters), (size_t(kRing) * ws.snapshot_words() + kMiscWords) * sizeof(uint32_t),
+                              hipHostMallocDefault));
+        for (hipEvent_t& e : ws.ring_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ws.cap_slots = padded;
         ws.frame_cap = n_frames;
     }
     // a smaller request reuses the buffers with fewer shards in play; counters are laid out for this request
     ws.n_shards = n_shards;
+    const size_t K = n_shards;
     ws.q[0].count = ws.counters;
-    ws.q[1].count = ws.counters + n_shards;
-    ws.hq.count = ws.counters + 2 * size_t(n_shards);
-    ws.sh.count = ws.counters + 3 * size_t(n_shards);
-    ws.fetch_e = ws.counters + 4 * size_t(n_shards);
-    ws.fetch_s = ws.counters + 5 * size_t(n_shards);
-    ws.dqe.count = ws.counters + 6 * size_t(n_shards);
-    ws.dqs.count = ws.counters + 7 * size_t(n_shards);
-    ws.misc = ws.counters + 8 * size_t(n_shards);
+    ws.q[1].count = ws.counters + K;
+    ws.hit_count[0] = ws.counters + 2 * K;
+    ws.hit_count[1] = ws.counters + 3 * K;
+    ws.hq.count = ws.hit_count[0];
+    ws.sh.count = ws.counters + 4 * K;
+    ws.fetch_e = ws.counters + 5 * K;
+    ws.fetch_s = ws.counters + 6 * K;
+    ws.dqe.count = ws.counters + 7 * K;
+    ws.dqs.count = ws.counters + 8 * K;
+    ws.done_e = ws.counters + 9 * K;
+    ws.done_s = ws.counters + 10 * K;
+    ws.misc = ws.counters + ws.misc_offset();
     return PT_OK;
 }
 
@@ -475,6 +494,7 @@ int launch_generate(pt_hip_scene* s, const PassArgs& pa, Timer& tm, bool count) 
     Workspace& ws = s->ws;
     HIP_TRY(hipMemsetAsync(ws.counters, 0, ws.counter_words() * sizeof(uint32_t), g_stream));
     if (int rc = tm.begin(PT_K_GENERATE)) return rc;
+    ws.hq.count = ws.hit_count[0];
     if (count)
         hipLaunchKernelGGL(k_generate<Count>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.hq, ws.lbuf,
                            ws.misc);
@@ -483,85 +503,107 @@ int launch_generate(pt_hip_scene* s, const PassArgs& pa, Timer& tm, bool count) 
                            ws.lbuf, ws.misc);
     if (int rc = tm.end()) return rc;
     // every path that k_generate kept is also a hit-list entry at the same position
-    HIP_TRY(hipMemcpyAsync(ws.hq.count, ws.q[0].count, ws.n_shards * sizeof(uint32_t), hipMemcpyDeviceToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(ws.hit_count[0], ws.q[0].count, ws.n_shards * sizeof(uint32_t), hipMemcpyDeviceToDevice, g_stream));
     return PT_OK;
 }
 
-// The bounce loop shared by pt_hip_render_device and pt_hip_li; k_generate has filled path queue 0 and the hit list.
+// The bounce loop shared by pt_hip_render_device and pt_hip_li; k_generate has filled path queue 0 and hit list 0.
+//
+// The host never waits for a kernel it needs the result of right away.  After the shade of bounce b it queues a copy of
+// the queue counters into a pinned snapshot and launches shadow(b) and extend(b) without looking at it; the snapshot is
+// read before bounce b+1 is launched, by which time it has long arrived (shadow and extend are the long kernels).  That
+// is enough because every kernel walks its shard's queue with a block-stride loop bounded by the device-side counter, so
+// grids do not depend on the fills, and a shard's fill can only shrink from bounce to bounce (a path never leaves its
+// shard and produces at most one continuation and one shadow ray), so the fills of bounce b bound those of b+1.
+// Measured: letting the host run further ahead gains nothing (the gaps were never the syncs), and grids sized by stale
+// fills cost a lot -- a workgroup that finds nothing to do still takes ~0.2 us of dispatch (scratch + 12 KB LDS).
 int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bool count) {
     Workspace& ws = s->ws;
     const uint32_t K = ws.n_shards;
-    HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * size_t(K) * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
-    Fill hits = fill_of(ws.h_counters + 2 * size_t(K), K);
-    int cur = 0;
+    const size_t snap = ws.snapshot_words();
     const bool wave = pa.traversal == PT_TRAVERSE_FAST;
+    uint32_t bound = std::min<uint32_t>(kShard, pa.n_slots);  // upper bound of every shard fill from here on
+    bool finished = false;
+    uint32_t launched = 0, consumed = 0;  // snapshots queued / read; snapshot i describes bounce i (taken after its shade)
+    auto consume = [&](bool wait) -> int {
+        while (consumed < launched) {
+            hipEvent_t ev = ws.ring_ev[consumed % kRing];
+            if (wait) {
+                HIP_TRY(hipEventSynchronize(ev));
+            } else {
+                const hipError_t q = hipEventQuery(ev);
+                if (q == hipErrorNotReady) return PT_OK;
+                HIP_TRY(q);
+            }
+            const uint32_t* c = ws.h_counters + size_t(consumed % kRing) * snap;
+            const int nxt = int(consumed & 1u) ^ 1;
+            const Fill next = fill_of(c + size_t(nxt) * K, K), shadow = fill_of(c + 4 * size_t(K), K);
+            if (st) {
+                st->any_rays += shadow.sum;
+                st->closest_rays += next.sum;
+            }
+            bound = std::min(bound, std::max(next.max, 1u));
+            if (next.max == 0) finished = true;
+            ++consumed;
+        }
+        return PT_OK;
+    };
     // every loop iteration is one bounce; specular chains do not advance the bounce counter (src/integrator.cpp:84-87),
     // so bound the loop independently
-    for (uint32_t iter = 0; hits.max > 0 && iter < 8 * pa.max_bounce; ++iter) {
-        const int nxt = cur ^ 1;
-        HIP_TRY(hipMemsetAsync(ws.q[nxt].count, 0, K * sizeof(uint32_t), g_stream));
-        HIP_TRY(hipMemsetAsync(ws.sh.count, 0, 5 * size_t(K) * sizeof(uint32_t), g_stream));  // shadow, both fetch, both deferred
+    for (uint32_t iter = 0; iter < 8 * pa.max_bounce; ++iter) {
+        if (int rc = consume(true)) return rc;  // the previous bounce's snapshot
+        if (finished) break;
+        const int cur = int(iter & 1u), nxt = cur ^ 1;
+        ws.hq.count = ws.hit_count[cur];
+        HitQ hq_next = ws.hq;
+        hq_next.count = ws.hit_count[nxt];
         if (int rc = tm.begin(PT_K_SHADE)) return rc;
-        hipLaunchKernelGGL(k_shade, dim3(blocks(hits.max, 256), K), dim3(256), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.q[nxt], ws.sh,
-                           ws.lbuf);
+        hipLaunchKernelGGL(k_shade, dim3(std::min(kShadeBlocks, blocks(bound, 256)), K), dim3(256), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.q[nxt], ws.sh, ws.lbuf,
+                           ZeroList{{hq_next.count, ws.fetch_e, ws.dqe.count, ws.done_e, nullptr}});
         if (int rc = tm.end()) return rc;
-        HIP_TRY(hipMemsetAsync(ws.hq.count, 0, K * sizeof(uint32_t), g_stream));
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.counters, 4 * size_t(K) * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipStreamSynchronize(g_stream));
-        const Fill next = fill_of(ws.h_counters + size_t(nxt) * K, K), shadow = fill_of(ws.h_counters + 3 * size_t(K), K);
-        if (shadow.max) {
+        HIP_TRY(hipMemcpyAsync(ws.h_counters + size_t(launched % kRing) * snap, ws.counters, snap * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipEventRecord(ws.ring_ev[launched % kRing], g_stream));
+        ++launched;
+        {
             if (int rc = tm.begin(PT_K_SHADOW)) return rc;
             if (wave) {
-                const dim3 grid(std::min(kWaveBlocks, blocks(shadow.max, kBlock)), K);
+                const dim3 grid(std::min(kWaveBlocks, blocks(bound, kBlock)), K);
                 const ShadowIo io{ws.sh, ws.dqs, ws.lbuf};
-                if (count) {
-                    hipLaunchKernelGGL(k_shadow_wave<Count>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_s, ws.misc);
-                    hipLaunchKernelGGL(k_shadow_deferred<Count>, dim3(1, K), dim3(kBlock), 0, g_stream, s->dev, ws.sh, ws.dqs, ws.lbuf, ws.misc);
-                } else {
-                    hipLaunchKernelGGL(k_shadow_wave<NoCount>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_s, ws.misc);
-                    hipLaunchKernelGGL(k_shadow_deferred<NoCount>, dim3(1, K), dim3(kBlock), 0, g_stream, s->dev, ws.sh, ws.dqs, ws.lbuf,
-                                       ws.misc);
-                }
+                if (count)
+                    hipLaunchKernelGGL(k_shadow_wave<Count>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_s, ws.done_s, ws.misc);
+                else
+                    hipLaunchKernelGGL(k_shadow_wave<NoCount>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_s, ws.done_s, ws.misc);
             } else if (count) {
-                hipLaunchKernelGGL(k_shadow<Count>, dim3(blocks(shadow.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.sh, pa.traversal,
-                                   ws.lbuf, ws.misc);
+                hipLaunchKernelGGL(k_shadow<Count>, dim3(std::min(kExactBlocks, blocks(bound, kBlock)), K), dim3(kBlock), 0, g_stream, s->dev, ws.sh, pa.traversal, ws.lbuf,
+                                   ws.misc);
             } else {
-                hipLaunchKernelGGL(k_shadow<NoCount>, dim3(blocks(shadow.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.sh,
-                                   pa.traversal, ws.lbuf, ws.misc);
+                hipLaunchKernelGGL(k_shadow<NoCount>, dim3(std::min(kExactBlocks, blocks(bound, kBlock)), K), dim3(kBlock), 0, g_stream, s->dev, ws.sh, pa.traversal,
+                                   ws.lbuf, ws.misc);
             }
             if (int rc = tm.end()) return rc;
         }
-        if (next.max) {
+        {
+            // clears what the NEXT bounce's shade and shadow accumulate into (this bounce's shadow kernel is done with them)
+            const ZeroList zl{{ws.q[cur].count, ws.sh.count, ws.fetch_s, ws.dqs.count, ws.done_s}};
             if (int rc = tm.begin(PT_K_EXTEND)) return rc;
             if (wave) {
-                const dim3 grid(std::min(kWaveBlocks, blocks(next.max, kBlock)), K);
-                const ExtendIo io{ws.q[nxt], ws.hq, ws.dqe};
-                if (count) {
-                    hipLaunchKernelGGL(k_extend_wave<Count>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_e, ws.misc);
-                    hipLaunchKernelGGL(k_extend_deferred<Count>, dim3(1, K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], ws.hq, ws.dqe, ws.misc);
-                } else {
-                    hipLaunchKernelGGL(k_extend_wave<NoCount>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_e, ws.misc);
-                    hipLaunchKernelGGL(k_extend_deferred<NoCount>, dim3(1, K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], ws.hq, ws.dqe,
-                                       ws.misc);
-                }
+                const dim3 grid(std::min(kWaveBlocks, blocks(bound, kBlock)), K);
+                const ExtendIo io{ws.q[nxt], hq_next, ws.dqe};
+                if (count)
+                    hipLaunchKernelGGL(k_extend_wave<Count>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_e, ws.done_e, zl, ws.misc);
+                else
+                    hipLaunchKernelGGL(k_extend_wave<NoCount>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_e, ws.done_e, zl, ws.misc);
             } else if (count) {
-                hipLaunchKernelGGL(k_extend<Count>, dim3(blocks(next.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], ws.hq,
-                                   pa.traversal, ws.misc);
+                hipLaunchKernelGGL(k_extend<Count>, dim3(std::min(kExactBlocks, blocks(bound, kBlock)), K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], hq_next,
+                                   pa.traversal, zl, ws.misc);
             } else {
-                hipLaunchKernelGGL(k_extend<NoCount>, dim3(blocks(next.max, kBlock), K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], ws.hq,
-                                   pa.traversal, ws.misc);
+                hipLaunchKernelGGL(k_extend<NoCount>, dim3(std::min(kExactBlocks, blocks(bound, kBlock)), K), dim3(kBlock), 0, g_stream, s->dev, ws.q[nxt], hq_next,
+                                   pa.traversal, zl, ws.misc);
             }
             if (int rc = tm.end()) return rc;
         }
-        if (st) {
-            st->any_rays += shadow.sum;
-            st->closest_rays += next.sum;
-        }
-        // the next hit list is a subset of the next path queue, shard by shard: its largest fill bounds the shade grid
-        hits = next;
-        cur = nxt;
     }
+    if (int rc = consume(true)) return rc;
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -840,14 +882,14 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         if (int rc = tm.begin(PT_K_FILM)) return rc;
         hipLaunchKernelGGL(k_film, dim3(((tiles_x + 1) / 2) * ((tiles_y + 1) / 2)), dim3(256), 0, g_stream, s->dev, pa, ws.lbuf, d_film);
         if (int rc = tm.end()) return rc;
-        HIP_TRY(hipMemcpyAsync(ws.h_counters, ws.misc, kMiscWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipMemcpyAsync(ws.h_misc(), ws.misc, kMiscWords * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));
         HIP_TRY(hipGetLastError());
         if (st) {
-            st->exact_retraces += ws.h_counters[0];
+            st->exact_retraces += ws.h_misc()[0];
             for (int k = 0; k < 3; ++k) {
-                st->nodes_fetched[k] += uint64_t(ws.h_counters[4 + 4 * k]) | (uint64_t(ws.h_counters[5 + 4 * k]) << 32);
-                st->tris_fetched[k] += uint64_t(ws.h_counters[6 + 4 * k]) | (uint64_t(ws.h_counters[7 + 4 * k]) << 32);
+                st->nodes_fetched[k] += uint64_t(ws.h_misc()[4 + 4 * k]) | (uint64_t(ws.h_misc()[5 + 4 * k]) << 32);
+                st->tris_fetched[k] += uint64_t(ws.h_misc()[6 + 4 * k]) | (uint64_t(ws.h_misc()[7 + 4 * k]) << 32);
             }
         }
         if (int rc = tm.collect(st)) return rc;
