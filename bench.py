@@ -138,6 +138,15 @@ def main():
             bvh[k] = {"nodes_per_ray": n_node, "tris_per_ray": n_tri}
             per_unit[k] += NODE_BYTES[a.traversal] * n_node + TRI_BYTES * n_tri
         achieved = units[dominant] * per_unit[dominant] / (kms[dominant] * 1e-3) / 1e9 if kms[dominant] > 0 else 0.0
+        # HBM-side bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be
+        # read from inside this process); the committed figure is quoted when it is for this workload and kernel
+        traffic, traffic_note = None, None
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s/%s" % (a.workload, a.traversal))
+            if t and t["kernel"] == "k_" + dominant and t["bytes_per_launch"]:
+                traffic, traffic_note = t["bytes_per_launch"], "%s; %s" % (t["source"], t["how"])
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "Mrays/s", "value": rays_total / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -150,7 +159,8 @@ def main():
             "kernel_launches_per_step": {k: v / a.steps for k, v in kn.items()},
             "bvh_records_per_ray": bvh,
             "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_note, "algorithmic_bytes_per_launch": per_unit[dominant] * units[dominant] / max(kn[dominant], 1),
                          "bytes_per_unit": per_unit[dominant], "units_per_launch": units[dominant] / max(kn[dominant], 1),
                          "avg_launch_ms": kms[dominant] / max(kn[dominant], 1)},
         }

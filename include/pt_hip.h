@@ -131,7 +131,7 @@ typedef struct pt_render_params {
     uint32_t max_bounce;       /* 32 in the reference (src/integrator.cpp:50); 0 selects 32 */
     int32_t  integrator;       /* PT_INTEGRATOR_* */
     int32_t  traversal;        /* PT_TRAVERSE_* */
-    uint32_t samples_per_pass; /* samples of every pixel in flight at once; 0 = about 8M paths in flight */
+    uint32_t samples_per_pass; /* samples of every pixel in flight at once; 0 = automatic (up to 128 M paths, 27 GB of queues) */
     uint32_t flags;            /* PT_FLAG_* */
     uint32_t reserved;
 } pt_render_params;
