@@ -9,17 +9,19 @@ import numpy as np
 from .scene import SceneData
 
 
-def _scene(name, verts, tris, mat_id, mats, light_infos, cam, normals=None, ni=None):
+def _scene(name, verts, tris, mat_id, mats, light_infos, cam, normals=None, ni=None, uvs=None, ti=None, mat_tex=None, textures=()):
     verts = np.asarray(verts, np.float32).reshape(-1, 3)
     vi = np.asarray(tris, np.uint32).reshape(-1, 3) + 1
     n = len(vi)
     return SceneData(
         name=name, verts=verts, normals=np.zeros((0, 3), np.float32) if normals is None else np.asarray(normals, np.float32),
-        uvs=np.zeros((0, 2), np.float32), vi=vi, ni=np.zeros((n, 3), np.uint32) if ni is None else np.asarray(ni, np.uint32),
-        ti=np.zeros((n, 3), np.uint32), mat_id=np.asarray(mat_id, np.uint32), mat_names=[m[0] for m in mats],
-        mat_kd=np.asarray([m[1] for m in mats], np.float32).reshape(-1, 3),
+        uvs=np.zeros((0, 2), np.float32) if uvs is None else np.asarray(uvs, np.float32),
+        vi=vi, ni=np.zeros((n, 3), np.uint32) if ni is None else np.asarray(ni, np.uint32),
+        ti=np.zeros((n, 3), np.uint32) if ti is None else np.asarray(ti, np.uint32), mat_id=np.asarray(mat_id, np.uint32),
+        mat_names=[m[0] for m in mats], mat_kd=np.asarray([m[1] for m in mats], np.float32).reshape(-1, 3),
         mat_ks=np.asarray([m[2] for m in mats], np.float32).reshape(-1, 3), mat_ns=np.asarray([m[3] for m in mats], np.float32),
-        mat_tex=np.full(len(mats), -1, np.int32), light_infos=light_infos, **cam)
+        mat_tex=np.full(len(mats), -1, np.int32) if mat_tex is None else np.asarray(mat_tex, np.int32),
+        textures=[np.asarray(t, np.float32) for t in textures], light_infos=light_infos, **cam)
 
 
 class _Mesh:
@@ -99,6 +101,41 @@ def grid_plane(n=16, width=64, height=64):
     mats = [("floor", (0.6, 0.6, 0.6), (0.2, 0.2, 0.2), 20.0), ("lamp", (0, 0, 0), (0, 0, 0), 1.0)]
     cam = dict(width=width, height=height, fovy=45.0, eye=(h, 6.0, -n * 0.8), lookat=(h, 0.0, h), up=(0.0, 1.0, 0.0))
     return _scene("grid%d" % n, m.v, m.t, m.m, mats, [("lamp", (30.0, 30.0, 30.0))], cam)
+
+
+def textured_room(width=96, height=72):
+    """Floor and back wall with texture coordinates (some outside [0, 1]: Bitmap::sample clamps, src/bitmap.cpp:153-154;
+    the second floor triangle has no texture indices: default uvs, src/shape.cpp:163-165), two textures of odd sizes, a
+    pyramid with per-vertex normals on two of its four faces (include/pt/mesh.h:37-44), a glossy untextured side wall
+    and a ceiling light."""
+    v = [(-2, 0, -2), (2, 0, -2), (2, 0, 2), (-2, 0, 2),            # floor 0..3
+         (-2, 0, 2), (2, 0, 2), (2, 3, 2), (-2, 3, 2),               # back wall 4..7
+         (-2, 0, -2), (-2, 0, 2), (-2, 3, 2), (-2, 3, -2),           # side wall 8..11
+         (-0.5, 2.9, -0.5), (0.5, 2.9, -0.5), (0.5, 2.9, 0.5), (-0.5, 2.9, 0.5),   # light 12..15
+         (0.2, 0, 0.2), (1.4, 0, 0.2), (1.4, 0, 1.4), (0.2, 0, 1.4), (0.8, 1.2, 0.8)]  # pyramid 16..20
+    tris = [(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (8, 9, 10), (8, 10, 11), (12, 13, 14), (12, 14, 15),
+            (16, 17, 20), (17, 18, 20), (18, 19, 20), (19, 16, 20)]
+    mat_id = [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 4, 4]
+    uvs = [(0, 0), (1, 0), (1, 1), (0, 1), (-0.25, 0.1), (1.3, 0.2), (1.2, 1.4), (-0.1, 0.9)]
+    ti = np.zeros((12, 3), np.uint32)
+    ti[0] = (1, 3, 2)
+    ti[2] = (5, 6, 7)
+    ti[3] = (5, 7, 8)
+    ti[8] = (1, 2, 3)       # the pyramid's material has no texture: indices present but unused
+    nrm = [(-0.3, 0.6, -0.7), (0.3, 0.6, -0.7), (0.0, 1.0, 0.0), (0.7, 0.6, 0.3)]
+    nrm = [tuple(np.asarray(n) / np.linalg.norm(n)) for n in nrm]
+    ni = np.zeros((12, 3), np.uint32)
+    ni[8] = (1, 2, 3)
+    ni[9] = (2, 4, 3)
+    yy, xx = np.mgrid[0:7, 0:11]
+    checker = np.where(((xx + yy) % 2)[..., None] == 0, np.array([0.8, 0.7, 0.2]), np.array([0.1, 0.15, 0.5])).astype(np.float32)
+    yy, xx = np.mgrid[0:5, 0:3]
+    ramp = np.stack([xx / 2.0, yy / 4.0, 0.25 + 0.0 * xx], -1).astype(np.float32)
+    mats = [("floor", (0.5, 0.5, 0.5), (0, 0, 0), 1.0), ("wall", (0.4, 0.4, 0.4), (0.1, 0.1, 0.1), 30.0),
+            ("side", (0.2, 0.3, 0.2), (0.4, 0.4, 0.4), 80.0), ("lamp", (0, 0, 0), (0, 0, 0), 1.0), ("pyr", (0.6, 0.3, 0.2), (0, 0, 0), 1.0)]
+    cam = dict(width=width, height=height, fovy=55.0, eye=(1.6, 1.4, -3.2), lookat=(0.0, 1.0, 1.0), up=(0.0, 1.0, 0.0))
+    return _scene("textured-room", v, tris, mat_id, mats, [("lamp", (25.0, 24.0, 22.0))], cam, normals=nrm, ni=ni, uvs=uvs, ti=ti,
+                  mat_tex=[0, 1, -1, -1, -1], textures=[checker, ramp])
 
 
 def _grid_box(lo, hi, n):

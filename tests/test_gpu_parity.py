@@ -212,7 +212,8 @@ def test_sample_ranges_add_up_and_pass_size_is_irrelevant(veach_gpu):
     assert np.allclose(a + b, c, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("make", [synth.cornell_box, lambda: synth.grid_plane(16, 96, 80), lambda: synth.random_soup(500, seed=8, width=100, height=76)])
+@pytest.mark.parametrize("make", [synth.cornell_box, lambda: synth.grid_plane(16, 96, 80), lambda: synth.random_soup(500, seed=8, width=100, height=76),
+                                  synth.textured_room])
 def test_rendering_parity_synthetic_scenes(make):
     sd = make()
     o, g = orc.Scene(sd), api.Scene(sd)
@@ -222,6 +223,27 @@ def test_rendering_parity_synthetic_scenes(make):
     assert helpers.rel_mse(api.film_to_image(film), orc.film_to_image(want)) < 1e-4
     assert np.allclose(film[..., 3], want[..., 3], rtol=1e-5, atol=1e-6)
     assert abs(st["closest_rays"] - ost["closest_rays"]) <= 2e-3 * ost["closest_rays"] + 2
+    g.close()
+
+
+def test_textured_materials_and_vertex_normals_match_oracle():
+    """Bitmap::sample (src/bitmap.cpp:146-166: clamp, bilinear, no flip), default uvs for faces without texture indices and
+    faces with / without per-vertex normals: base-colour and normal AOVs against the oracle, and per-sample radiance."""
+    sd = synth.textured_room()
+    o, g = orc.Scene(sd), api.Scene(sd)
+    for integ_g, integ_o in ((api.INTEGRATOR_ALBEDO, orc.INTEGRATOR_ALBEDO), (api.INTEGRATOR_NORMAL, orc.INTEGRATOR_NORMAL)):
+        film, _ = g.render(0, 8, integrator=integ_g, traversal=api.TRAVERSE_FAST)
+        want, _ = o.render(0, 8, integ_o)
+        assert np.allclose(film, want, rtol=1e-4, atol=2e-4)
+    img = api.film_to_image(g.render(0, 8, integrator=api.INTEGRATOR_ALBEDO)[0])
+    assert len(np.unique(np.round(img.reshape(-1, 3), 2), axis=0)) > 20      # the textures really show up
+    rng = np.random.default_rng(5)
+    xy = np.stack([rng.integers(0, sd.width, 600), rng.integers(0, sd.height, 600)], 1).astype(np.int32)
+    smp = rng.integers(0, 64, 600).astype(np.uint32)
+    got = g.li(xy, smp)[0]
+    want = np.array([o.li(int(x), int(y), int(s))["rgb"] for (x, y), s in zip(xy, smp)], np.float32)
+    err = np.abs(got - want).max(1) / (np.abs(want).max(1) + 1e-3)
+    assert (err < 1e-3).mean() >= 0.99
     g.close()
 
 

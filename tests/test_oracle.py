@@ -288,3 +288,44 @@ def test_li_ray_log_and_dimensions(veach_oracle):
     n_closest = int((rays[:, 8] == 0).sum())
     assert 2 + 6 * (n_closest - 1) <= r["dims"] <= 2 + 7 * n_closest
     assert np.isfinite(r["rgb"]).all() and (r["rgb"] >= 0).all()
+
+
+def test_texture_lookup_against_numpy_restatement():
+    """Base-colour AOV samples on the textured floor / wall against an independent numpy version of Bitmap::sample
+    (src/bitmap.cpp:146-166: clamp to [0,1], s = max(u*cols - 0.5, 0), bilinear with clamped upper texel, no flip) fed
+    with the uv interpolation of Intersection::complete (src/shape.cpp:163-165)."""
+    from pt_hip import synth
+    sd = synth.textured_room()
+    o = orc.Scene(sd)
+
+    def sample(tex, uv):
+        h, w = tex.shape[:2]
+        u, v = np.clip(uv, 0.0, 1.0).astype(np.float32)
+        s, t = max(np.float32(u * w) - np.float32(0.5), np.float32(0)), max(np.float32(v * h) - np.float32(0.5), np.float32(0))
+        x0, y0 = int(s), int(t)
+        x1, y1 = min(x0 + 1, w - 1), min(y0 + 1, h - 1)
+        a, b = float(s - x0), float(t - y0)
+        mix = lambda p, q, f: p.astype(np.float64) * (1.0 - f) + (q * np.float32(f)).astype(np.float64)
+        top, bot = mix(tex[y0, x0], tex[y0, x1], a).astype(np.float32), mix(tex[y1, x0], tex[y1, x1], a).astype(np.float32)
+        return mix(top, bot, b).astype(np.float32)
+
+    checked = 0
+    for px in range(0, sd.width, 5):
+        for py in range(0, sd.height, 5):
+            sx, sy = o.pixel_sample(px, py, 3)
+            ray = o.camera_ray(sx, sy)
+            hit = o.intersect(ray[None])[0]
+            prim = int(hit["prim"])
+            if prim < 0 or sd.mat_tex[sd.mat_id[prim]] < 0:
+                continue
+            b = hit["bary"]
+            if sd.ti[prim, 0]:
+                c = sd.uvs[sd.ti[prim] - 1]
+            else:
+                c = np.array([(0, 0), (1, 0), (1, 1)], np.float32)
+            uv = b[0] * c[0] + (b[1] * c[1] + b[2] * c[2])
+            want = sample(sd.textures[sd.mat_tex[sd.mat_id[prim]]], uv)
+            got = o.li(px, py, 3, orc.INTEGRATOR_ALBEDO)["rgb"]
+            assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (px, py, prim, got, want)
+            checked += 1
+    assert checked > 50
