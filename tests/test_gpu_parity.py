@@ -297,3 +297,50 @@ def test_command_line_front_end_writes_the_same_images(tmp_path):
         assert got.shape == want.shape
         assert np.allclose(got, want, rtol=1e-5, atol=1e-7), stem
     g.close()
+
+
+# ------------------------------------------------------------------------------------------------ full-size workload
+
+def test_full_size_library_workload_properties():
+    """The bench workload at its full size (1.64 M triangles, 1280x720).  The oracle checks what it can do in seconds
+    (30 k rays, one sample per pixel); beyond that the size-independent properties: the two traversal orders agree bit
+    for bit on a million random rays, and films of disjoint sample ranges add up."""
+    sd = synth.library_synth(detail=8)
+    o, g = orc.Scene(sd), api.Scene(sd)
+    closest, shadow = helpers.recorded_rays(o, 400, seed=11)
+    prim = helpers.primary_rays(o, sample=2, step=9)
+    rays = np.concatenate([prim, closest])
+    want = o.intersect(rays)
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_EXACT), want).all()
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_FAST), want).all()
+    occ, first = o.occluded(shadow)
+    g_occ, g_first = g.occluded(shadow, api.TRAVERSE_EXACT)
+    assert np.array_equal(g_occ, occ) and np.array_equal(g_first, first)
+    assert np.array_equal(g.occluded(shadow, api.TRAVERSE_FAST)[0], occ)
+
+    rng = np.random.default_rng(3)
+    n = 1 << 20
+    org = rng.uniform([-1.9, 0.05, -1.4], [1.9, 2.55, 1.4], (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::1000, 1] = 0.0                                    # some axis-parallel rays (plain-division path)
+    big = np.concatenate([org, d, np.zeros((n, 1), np.float32), np.full((n, 1), np.inf, np.float32)], 1).astype(np.float32)
+    he, hf = g.intersect(big, api.TRAVERSE_EXACT), g.intersect(big, api.TRAVERSE_FAST)
+    assert np.array_equal(he.view(np.uint32), hf.view(np.uint32))
+    assert (he["prim"] >= 0).mean() > 0.99                # a closed room
+    sub = slice(0, n, 53)
+    assert helpers.hits_equal(he[sub], o.intersect(big[sub])).all()
+    big[:, 7] = rng.uniform(0.05, 3.0, n).astype(np.float32)
+    oe, _ = g.occluded(big, api.TRAVERSE_EXACT)
+    assert np.array_equal(oe, g.occluded(big, api.TRAVERSE_FAST)[0])
+    assert np.array_equal(oe[sub], o.occluded(big[sub])[0])
+
+    a, sa = g.render(0, 1, traversal=api.TRAVERSE_FAST)
+    b, sb = g.render(1, 3, traversal=api.TRAVERSE_FAST)
+    c, sc = g.render(0, 3, traversal=api.TRAVERSE_FAST)
+    assert sa["closest_rays"] + sb["closest_rays"] == sc["closest_rays"] and sa["any_rays"] + sb["any_rays"] == sc["any_rays"]
+    assert np.allclose(a + b, c, rtol=1e-5, atol=1e-5)
+    want, ost = o.render(0, 1, nthreads=16)
+    assert helpers.rel_mse(api.film_to_image(a), orc.film_to_image(want)) < 1e-4
+    assert abs(sa["closest_rays"] - ost["closest_rays"]) <= 1e-4 * ost["closest_rays"]
+    g.close()
