@@ -255,6 +255,129 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
     }
 }
 
+// ------------------------------------------------------------------------------------------------ generate, wave-refill
+
+// Ordered-mode k_generate: the "queue" of shard s is its kShard sample slots, a lane that takes slot j builds the camera
+// ray on the spot (closest_wave), and the result goes where k_generate puts it.
+struct GenerateIo {
+    PassArgs pa;
+    PathQ q;
+    HitQ hq;
+    DeferQ dq;
+    float4* lbuf;
+    struct Carry {
+        uint32_t pix, frame;
+    };
+    PTD uint32_t count(uint32_t shard) const { return min(kShard, pa.n_slots - shard * kShard); }
+    PTD bool load(const DevScene& sc, uint32_t shard, uint32_t j, RayD& ray, Carry& c) const {
+        const uint32_t slot = shard * kShard + j;
+        uint32_t px, py, frame;
+        if (pa.list_xy) {
+            px = uint32_t(pa.list_xy[2 * size_t(slot)]);
+            py = uint32_t(pa.list_xy[2 * size_t(slot) + 1]);
+            frame = pa.list_frame[slot];
+        } else {
+            const uint32_t lane = slot & 63u, ws = slot >> 6;
+            frame = ws % pa.spp_pass;
+            const uint32_t tile = ws / pa.spp_pass;
+            px = (tile % pa.tiles_x) * 8u + (lane & 7u);
+            py = (tile / pa.tiles_x) * 8u + (lane >> 3);
+        }
+        c.pix = px | (py << 16);
+        c.frame = frame;
+        ray = RayD{V3{0.0f, 0.0f, 0.0f}, V3{1.0f, 1.0f, 1.0f}, 0.0f, 0.0f};
+        if (!(px < sc.cam.width && py < sc.cam.height)) return false;
+        const V2 jit = pixel_jitter(sc, pa.frame_tab + size_t(frame) * 1024u, px, py);
+        const V2 ps{float(int(px)) + jit.x, float(int(py)) + jit.y};
+        if (pa.list_pixel_sample) {
+            pa.list_pixel_sample[2 * size_t(slot)] = ps.x;
+            pa.list_pixel_sample[2 * size_t(slot) + 1] = ps.y;
+        }
+        camera_ray(sc.cam, ps, ray.o, ray.d, ray.tmin, ray.tmax);
+        return true;
+    }
+    // what k_generate does with the result of slot j: AOVs are final, path-traced samples enter the queues
+    PTD void emit(const DevScene& sc, uint32_t shard, bool have, uint32_t j, const HitD& h, const Carry& c, const V3& o, const V3& d) const {
+        const size_t sbase = size_t(shard) * kShard;
+        bool alive = have && h.prim >= 0;
+        if (have) {
+            V3 out = mk3(0.0f);
+            if (alive && pa.integrator != 0) {
+                TriRec t;
+                t.load(sc, uint32_t(h.prim));
+                if (pa.integrator == 1) {
+                    Surf it;
+                    complete(t, h.u, h.v, it);
+                    out = it.n;
+                } else {
+                    out = surface_material(sc, t, uint32_t(h.prim), h.u, h.v).kd;
+                }
+                alive = false;
+            }
+            lbuf[sbase + j] = make_float4(out.x, out.y, out.z, 0.0f);
+        }
+        const uint32_t local = wave_alloc(alive, q.count + shard);
+        if (alive) {
+            const size_t dst = sbase + local;
+            const uint32_t meta = 2u | (0u << 10) | (c.frame << 16);
+            q.a[dst] = make_float4(o.x, o.y, o.z, d.x);
+            q.b[dst] = make_float4(d.y, d.z, 1.0f, 1.0f);
+            q.c[dst] = make_float4(1.0f, 0.0f, as_f(c.pix), as_f(meta));
+            q.slot[dst] = uint32_t(sbase + j);
+            hq.h0[dst] = make_float4(as_f(local), as_f(uint32_t(h.prim)), h.u, h.v);
+            hq.h1[dst] = make_float4(as_f(c.pix), as_f(meta), h.t, 0.0f);
+        }
+    }
+    PTD void commit(const DevScene& sc, uint32_t shard, bool fin, uint32_t j, const HitD& h, bool defer, float bound, const Carry& c, const V3& o,
+                    const V3& d) const {
+        emit(sc, shard, fin && !defer, j, h, c, o, d);
+        const bool df = fin && defer;
+        if (__any(df)) {
+            const uint32_t dl = wave_alloc(df, dq.count + shard);
+            if (df) {
+                store_shared(&dq.e[size_t(shard) * kShard + dl].x, j);
+                store_shared(&dq.e[size_t(shard) * kShard + dl].y, as_u(bound));
+            }
+        }
+    }
+};
+
+template <class C>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_generate_wave(DevScene sc, GenerateIo io,
+                                                                                                                  uint32_t* fetch, uint32_t* done,
+                                                                                                                  uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    const uint32_t shard = blockIdx.y;
+    C wc;
+    closest_wave(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
+    if (last_block_of_shard(done, shard)) {
+        const size_t sbase = size_t(shard) * kShard;
+        const uint32_t n = load_fresh(io.dq.count + shard);
+        for (uint32_t base = 0; base < n; base += kBlock) {
+            const uint32_t k = base + threadIdx.x;
+            HitD h{-1, 0.0f, 0.0f, 0.0f};
+            uint32_t j = 0;
+            GenerateIo::Carry c{};
+            RayD ray{};
+            if (k < n) {
+                j = load_fresh(&io.dq.e[sbase + k].x);
+                const float bound = as_f(load_fresh(&io.dq.e[sbase + k].y));
+                io.load(sc, shard, j, ray, c);
+                bool redo = true;
+                if (bound == __builtin_huge_valf()) {
+                    closest_fast(sc, ray, h, redo, s_stack + threadIdx.x, wc);
+                } else {
+                    const RayPre pre = make_pre(sc, ray);
+                    closest_exact_t<false>(sc, ray, pre, bound, h, s_stack + threadIdx.x, wc);
+                }
+                if (redo && misc) atomicAdd(misc, 1u);
+            }
+            io.emit(sc, shard, k < n, j, h, c, ray.o, ray.d);
+        }
+    }
+    flush_counts(wc, misc, 0);
+}
+
 // ------------------------------------------------------------------------------------------------ extend (bounce >= 1)
 
 // Scene::rayIntersect for rays spawned by Intersection::genRay (src/shape.cpp:186-189): tmin 0, tmax +inf.
@@ -299,14 +422,15 @@ struct ExtendIo {
         float pix, meta;
     };
     PTD uint32_t count(uint32_t shard) const { return q.count[shard]; }
-    PTD void load(uint32_t shard, uint32_t j, RayD& ray, Carry& c) const {
+    PTD bool load(const DevScene&, uint32_t shard, uint32_t j, RayD& ray, Carry& c) const {
         const size_t i = size_t(shard) * kShard + j;
         const float4 a = q.a[i], b = q.b[i], cc = q.c[i];
         ray = RayD{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
         c.pix = cc.z;
         c.meta = cc.w;
+        return true;
     }
-    PTD void commit(uint32_t shard, bool fin, uint32_t j, const HitD& h, bool defer, float bound, const Carry& c) const {
+    PTD void commit(const DevScene&, uint32_t shard, bool fin, uint32_t j, const HitD& h, bool defer, float bound, const Carry& c, const V3&, const V3&) const {
         const size_t sbase = size_t(shard) * kShard;
         const bool found = fin && !defer && h.prim >= 0;
         const uint32_t local = wave_alloc(found, hq.count + shard);
@@ -384,13 +508,13 @@ struct ShadowIo {
         uint32_t slot;
     };
     PTD uint32_t count(uint32_t shard) const { return sh.count[shard]; }
-    PTD void load(uint32_t shard, uint32_t j, RayD& ray, Carry& c) const {
+    PTD void load(const DevScene&, uint32_t shard, uint32_t j, RayD& ray, Carry& c) const {
         const size_t i = size_t(shard) * kShard + j;
         const float4 a = sh.a[i], b = sh.b[i];
         ray = RayD{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
         c.slot = as_u(b.w);
     }
-    PTD void commit(uint32_t shard, bool fin, uint32_t j, bool occluded, bool defer, const Carry& c) const {
+    PTD void commit(const DevScene&, uint32_t shard, bool fin, uint32_t j, bool occluded, bool defer, const Carry& c) const {
         const size_t sbase = size_t(shard) * kShard;
         if (fin && !defer && !occluded) {
             const float4 v = sh.c[sbase + j];
@@ -446,12 +570,13 @@ struct BatchClosestIo {
     float4* hits;
     struct Carry {};
     PTD uint32_t count(uint32_t shard) const { return min(kShard, n - shard * kShard); }
-    PTD void load(uint32_t shard, uint32_t j, RayD& ray, Carry&) const {
+    PTD bool load(const DevScene&, uint32_t shard, uint32_t j, RayD& ray, Carry&) const {
         const size_t i = size_t(shard) * kShard + j;
         const float4 r0 = rays[2 * i], r1 = rays[2 * i + 1];
         ray = RayD{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
+        return true;
     }
-    PTD void commit(uint32_t shard, bool fin, uint32_t j, const HitD& h, bool defer, float bound, const Carry&) const {
+    PTD void commit(const DevScene&, uint32_t shard, bool fin, uint32_t j, const HitD& h, bool defer, float bound, const Carry&, const V3&, const V3&) const {
         if (!fin) return;
         const size_t i = size_t(shard) * kShard + j;
         hits[i] = defer ? make_float4(as_f(kBatchDeferred), bound, 0.0f, 0.0f) : make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
@@ -497,12 +622,12 @@ struct BatchAnyIo {
     uint8_t* occ;
     struct Carry {};
     PTD uint32_t count(uint32_t shard) const { return min(kShard, n - shard * kShard); }
-    PTD void load(uint32_t shard, uint32_t j, RayD& ray, Carry&) const {
+    PTD void load(const DevScene&, uint32_t shard, uint32_t j, RayD& ray, Carry&) const {
         const size_t i = size_t(shard) * kShard + j;
         const float4 r0 = rays[2 * i], r1 = rays[2 * i + 1];
         ray = RayD{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
     }
-    PTD void commit(uint32_t shard, bool fin, uint32_t j, bool occluded, bool defer, const Carry&) const {
+    PTD void commit(const DevScene&, uint32_t shard, bool fin, uint32_t j, bool occluded, bool defer, const Carry&) const {
         if (fin) occ[size_t(shard) * kShard + j] = defer ? uint8_t(2) : uint8_t(occluded ? 1 : 0);
     }
 };

@@ -497,12 +497,22 @@ int launch_generate(pt_hip_scene* s, const PassArgs& pa, Timer& tm, bool count) 
     HIP_TRY(hipMemsetAsync(ws.counters, 0, ws.counter_words() * sizeof(uint32_t), g_stream));
     if (int rc = tm.begin(PT_K_GENERATE)) return rc;
     ws.hq.count = ws.hit_count[0];
-    if (count)
+    if (pa.traversal == PT_TRAVERSE_FAST) {
+        // the extend kernel's fetch / deferred / done counters are free until the first extend (zeroed above, and again by
+        // the first shade)
+        const GenerateIo io{pa, ws.q[0], ws.hq, ws.dqe, ws.lbuf};
+        const dim3 grid(std::min(kWaveBlocks, blocks(pa.n_slots, kBlock)), ws.n_shards);
+        if (count)
+            hipLaunchKernelGGL(k_generate_wave<Count>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_e, ws.done_e, ws.misc);
+        else
+            hipLaunchKernelGGL(k_generate_wave<NoCount>, grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_e, ws.done_e, ws.misc);
+    } else if (count) {
         hipLaunchKernelGGL(k_generate<Count>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.hq, ws.lbuf,
                            ws.misc);
-    else
+    } else {
         hipLaunchKernelGGL(k_generate<NoCount>, dim3(blocks(pa.n_slots, kBlock)), dim3(kBlock), 0, g_stream, s->dev, pa, ws.q[0], ws.hq,
                            ws.lbuf, ws.misc);
+    }
     if (int rc = tm.end()) return rc;
     // every path that k_generate kept is also a hit-list entry at the same position
     HIP_TRY(hipMemcpyAsync(ws.hit_count[0], ws.q[0].count, ws.n_shards * sizeof(uint32_t), hipMemcpyDeviceToDevice, g_stream));

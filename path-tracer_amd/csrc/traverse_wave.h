@@ -176,8 +176,9 @@ PTD uint32_t wave_fetch(bool want, uint32_t* counter, uint32_t count, bool& more
 
 // Closest hit for the rays of one shard.  Io supplies
 //   uint32_t count(shard)                                   rays in the shard's queue
-//   void load(shard, j, RayD&, Carry&)                      ray j and whatever the caller wants back at commit time
-//   void commit(shard, fin, j, hit, defer, bound, carry)    called by the whole wave; fin marks lanes with a result
+//   bool load(sc, shard, j, RayD&, Carry&)                     ray j and whatever the caller wants back at commit time;
+//                                                           false = position j holds no query (reported as a miss)
+//   void commit(sc, shard, fin, j, hit, defer, bound, carry, o, d)   called by the whole wave; fin marks lanes with a result
 template <class Io, class C>
 PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, C& wc) {
     const uint32_t count = io.count(shard);
@@ -194,7 +195,7 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
     float bound = 0.0f;
     for (;;) {
         if (__any(state == kLaneDone)) {
-            io.commit(shard, state == kLaneDone, j, L.hit, defer, bound, carry);
+            io.commit(sc, shard, state == kLaneDone, j, L.hit, defer, bound, carry, L.pre.o, L.pre.d);
             if (state == kLaneDone) state = kLaneEmpty;
         }
         if (more) {
@@ -203,9 +204,14 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
             if (want && jj < count) {
                 j = jj;
                 RayD ray;
-                io.load(shard, j, ray, carry);
+                const bool has_ray = io.load(sc, shard, j, ray, carry);
                 const RayPre pre = make_pre(sc, ray);
-                if (pre.special) {
+                L.pre = pre;
+                if (!has_ray) {  // a queue position without a query (a pixel slot outside the image)
+                    state = kLaneDone;
+                    defer = false;
+                    L.hit.prim = -1;
+                } else if (pre.special) {
                     state = kLaneDone;
                     defer = true;
                     bound = __builtin_huge_valf();
@@ -242,8 +248,8 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
     }
 }
 
-// Any hit for the rays of one shard.  Io: count(shard), load(shard, j, RayD&, Carry&),
-// commit(shard, fin, j, occluded, defer, carry) -- per lane, no wave-level operation required.
+// Any hit for the rays of one shard.  Io: count(shard), load(sc, shard, j, RayD&, Carry&),
+// commit(sc, shard, fin, j, occluded, defer, carry) -- per lane, no wave-level operation required.
 template <class Io, class C>
 PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, C& wc) {
     const uint32_t count = io.count(shard);
@@ -259,7 +265,7 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
     bool defer = false, more = true;
     for (;;) {
         if (__any(state == kLaneDone)) {
-            io.commit(shard, state == kLaneDone, j, L.occluded, defer, carry);
+            io.commit(sc, shard, state == kLaneDone, j, L.occluded, defer, carry);
             if (state == kLaneDone) state = kLaneEmpty;
         }
         if (more) {
@@ -268,7 +274,7 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
             if (want && jj < count) {
                 j = jj;
                 RayD ray;
-                io.load(shard, j, ray, carry);
+                io.load(sc, shard, j, ray, carry);
                 const RayPre pre = make_pre(sc, ray);
                 if (pre.special) {
                     state = kLaneDone;
