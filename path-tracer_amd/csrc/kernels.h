@@ -90,7 +90,7 @@ PTD bool last_block_of_shard(uint32_t* done, uint32_t shard) {
 #endif
 constexpr uint32_t kMaxWaveBlocks = 8;  // workgroups per shard of the wave-refill kernels: between 2 and 8, see wave_blocks()
 constexpr uint32_t kMinWaveBlocks = 2;
-constexpr uint32_t kShadeBlocks = 8;  // workgroups per shard of k_shade (256 threads each)
+constexpr uint32_t kShadeBlocks = 8;  // most workgroups per shard of k_shade (256 threads each), see shade_blocks()
 constexpr uint32_t kExactBlocks = 16; // workgroups per shard of the reference-order traversal kernels  // workgroups per shard of a wave-refill kernel: 16 waves share a shard's queue
 
 struct PassArgs {
