@@ -38,6 +38,9 @@ def load_workload(name):
         return SceneData.load(os.path.join(ROOT, "tests", "golden", "veach_mis_scene.npz")), "veach-mis (reference mesh, 3092 tris, 3040 emitters) 1280x720"
     if name == "cornell-box-synth":
         return synth.cornell_box(), "cornell-box-synth (stand-in: reference mesh not in its tree) 768x768"
+    if name == "bathroom-synth":
+        sd = synth.bathroom_synth()
+        return sd, "bathroom-synth (stand-in: reference mesh not in its tree, %d tris, 5 procedural textures) 768x768" % sd.n_tris
     if name == "library-synth":
         sd = synth.library_synth(detail=8)
         return sd, "library-synth (stand-in: reference mesh not in its tree, %d tris) 1280x720" % sd.n_tris

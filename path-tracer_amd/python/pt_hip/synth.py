@@ -106,8 +106,9 @@ def grid_plane(n=16, width=64, height=64):
 def textured_room(width=96, height=72):
     """Floor and back wall with texture coordinates (some outside [0, 1]: Bitmap::sample clamps, src/bitmap.cpp:153-154;
     the second floor triangle has no texture indices: default uvs, src/shape.cpp:163-165), two textures of odd sizes, a
-    pyramid with per-vertex normals on two of its four faces (include/pt/mesh.h:37-44), a glossy untextured side wall
-    and a ceiling light."""
+    pyramid with per-vertex normals on two of its four faces (include/pt/mesh.h:37-44), a side wall that is a perfect
+    mirror (a Ks component above 999, src/material.cpp:24,46,94: the specular branch of the integrator,
+    src/integrator.cpp:84-87) and a ceiling light."""
     v = [(-2, 0, -2), (2, 0, -2), (2, 0, 2), (-2, 0, 2),            # floor 0..3
          (-2, 0, 2), (2, 0, 2), (2, 3, 2), (-2, 3, 2),               # back wall 4..7
          (-2, 0, -2), (-2, 0, 2), (-2, 3, 2), (-2, 3, -2),           # side wall 8..11
@@ -132,7 +133,7 @@ def textured_room(width=96, height=72):
     yy, xx = np.mgrid[0:5, 0:3]
     ramp = np.stack([xx / 2.0, yy / 4.0, 0.25 + 0.0 * xx], -1).astype(np.float32)
     mats = [("floor", (0.5, 0.5, 0.5), (0, 0, 0), 1.0), ("wall", (0.4, 0.4, 0.4), (0.1, 0.1, 0.1), 30.0),
-            ("side", (0.2, 0.3, 0.2), (0.4, 0.4, 0.4), 80.0), ("lamp", (0, 0, 0), (0, 0, 0), 1.0), ("pyr", (0.6, 0.3, 0.2), (0, 0, 0), 1.0)]
+            ("side", (0.0, 0.0, 0.0), (1000.0, 1000.0, 1000.0), 1.0), ("lamp", (0, 0, 0), (0, 0, 0), 1.0), ("pyr", (0.6, 0.3, 0.2), (0, 0, 0), 1.0)]
     cam = dict(width=width, height=height, fovy=55.0, eye=(1.6, 1.4, -3.2), lookat=(0.0, 1.0, 1.0), up=(0.0, 1.0, 0.0))
     return _scene("textured-room", v, tris, mat_id, mats, [("lamp", (25.0, 24.0, 22.0))], cam, normals=nrm, ni=ni, uvs=uvs, ti=ti,
                   mat_tex=[0, 1, -1, -1, -1], textures=[checker, ramp])
@@ -260,3 +261,96 @@ def library_synth(detail=4, seed=0x11B4A47, width=1280, height=720):
                lookat=(float(np.float32(0.2)), float(np.float32(1.2)), float(np.float32(0.7))), up=(0.0, 1.0, 0.0))
     lights = [("Sconce_Glass.001", (26.0, 26.0, 26.0)), ("Sconce_Glass", (16.0, 14.0, 8.0))]
     return _scene("library-synth", np.concatenate(V), np.concatenate(T), np.concatenate(M), mats, lights, cam)
+
+
+def _grid_quad(origin, eu, ev, n, uv_lo=(0.0, 0.0), uv_hi=(1.0, 1.0)):
+    """Parallelogram origin + a*eu + b*ev tessellated into n x n quads, with texture coordinates running from uv_lo to uv_hi."""
+    t = np.linspace(0.0, 1.0, n + 1)
+    a, b = np.meshgrid(t, t, indexing="ij")
+    a, b = a.ravel(), b.ravel()
+    verts = np.asarray(origin, np.float64) + a[:, None] * np.asarray(eu, np.float64) + b[:, None] * np.asarray(ev, np.float64)
+    uvs = np.stack([uv_lo[0] + a * (uv_hi[0] - uv_lo[0]), uv_lo[1] + b * (uv_hi[1] - uv_lo[1])], 1)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    q00, q10, q11, q01 = i * (n + 1) + j, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1, i * (n + 1) + j + 1
+    tris = np.concatenate([np.stack([q00, q10, q11], 1), np.stack([q00, q11, q01], 1)])
+    return verts, uvs, tris
+
+
+def _procedural_textures():
+    """Stand-ins for the bathroom's texture files (tiles, marble, wood, rug, picture), linear RGB float."""
+    yy, xx = np.mgrid[0:256, 0:256].astype(np.float32)
+    tiles = np.where((((xx // 32) + (yy // 32)) % 2)[..., None] == 0, np.float32([0.75, 0.75, 0.7]), np.float32([0.25, 0.3, 0.35]))
+    tiles = tiles * np.where(((xx % 32 < 2) | (yy % 32 < 2))[..., None], np.float32(0.3), np.float32(1.0))
+    marble = 0.6 + 0.25 * np.sin(xx / 17.0 + 3.0 * np.sin(yy / 29.0))[..., None] * np.float32([1.0, 0.95, 0.9])
+    wood = np.float32([0.45, 0.28, 0.15]) * (0.7 + 0.3 * np.sin(yy / 3.0 + 2.0 * np.sin(xx / 40.0)))[..., None]
+    rug = np.float32([0.5, 0.1, 0.1]) * (0.6 + 0.4 * (((xx // 8) + (yy // 8)) % 2))[..., None]
+    pic = np.stack([xx / 255.0, yy / 255.0, 0.5 + 0.5 * np.sin((xx + yy) / 20.0)], -1)
+    return [np.clip(t, 0.0, 1.0).astype(np.float32) for t in (tiles, marble, wood, rug, pic)]
+
+
+def bathroom_synth(detail=9, width=768, height=768):
+    """Stand-in for the reference's bathroom scene, whose mesh is not in its tree: a tiled room with a tub, a vanity, a
+    glossy wall panel, spheres and cylinders-as-prisms of the metal materials, a rug and a picture, lit by one ceiling panel.
+    Camera and light are those of scenes/bathroom/bathroom.xml; material values are taken from bathroom.mtl (Floor, Marble,
+    Wood, Rug, Painting1 textured; Mirror, StainlessSmooth, StainlessRough, Bathtube, GreyWall, Light untextured); the
+    texture images are procedural.  Triangle count grows with detail^2 (detail 9: about 0.47 M)."""
+    TILES, MARBLE, WOODT, RUGT, PIC = range(5)
+    mats = [("Floor", (0, 0, 0), (0, 0, 0), 4.0, TILES), ("Marble", (0.5, 0.5, 0.5), (0, 0, 0), 1.0, MARBLE),
+            ("Wood", (0, 0, 0), (0, 0, 0), 6.0, WOODT), ("Rug", (0.5, 0.5, 0.5), (0, 0, 0), 1.0, RUGT),
+            ("Painting1", (0.5, 0.5, 0.5), (0, 0, 0), 1.0, PIC), ("Mirror", (0, 0, 0), (1, 1, 1), 10000.0, -1),
+            ("StainlessSmooth", (0.2, 0.3, 0.4), (0.2, 0.3, 0.4), 6.0, -1), ("StainlessRough", (0.8, 0.7, 0.8), (0.8, 0.7, 0.8), 9.0, -1),
+            ("Bathtube", (0.612066, 0.612066, 0.612066), (0.612066, 0.612066, 0.612066), 1000.0, -1),
+            ("GreyWall", (0.893289, 0.893289, 0.893289), (0, 0, 0), 1.0, -1), ("Light", (0, 0, 0), (0, 0, 0), 1.0, -1)]
+    FLOOR, MARB, WOOD, RUG, PAINT, MIRROR, SSMOOTH, SROUGH, TUB, WALL, LIGHT = range(11)
+    V, U, T, TI, M = [], [], [], [], []
+    nv = nu = 0
+
+    def add(verts, tris, mat, uvs=None):
+        nonlocal nv, nu
+        V.append(verts)
+        T.append(tris + nv)
+        M.append(np.full(len(tris), mat))
+        if uvs is None:
+            TI.append(np.zeros((len(tris), 3), np.int64))
+        else:
+            U.append(uvs)
+            TI.append(tris + nu + 1)
+            nu += len(uvs)
+        nv += len(verts)
+
+    def quad(vut, mat, textured=True):
+        verts, uvs, tris = vut
+        add(verts, tris, mat, uvs if textured else None)
+
+    X0, X1, Y0, Y1, Z0, Z1 = -3.6, 0.9, 0.0, 2.5, -3.5, 0.9
+    n_big = max(2, 24 * detail)
+    quad(_grid_quad((X0, Y0, Z0), (0, 0, Z1 - Z0), (X1 - X0, 0, 0), n_big), FLOOR)                 # floor, normal +y
+    quad(_grid_quad((X0, Y1, Z0), (X1 - X0, 0, 0), (0, 0, Z1 - Z0), n_big // 2), WALL, False)     # ceiling
+    quad(_grid_quad((X0, Y0, Z0), (X1 - X0, 0, 0), (0, Y1, 0), n_big), MARB)                      # wall z = Z0
+    quad(_grid_quad((X0, Y0, Z0), (0, Y1, 0), (0, 0, Z1 - Z0), n_big), MARB)                      # wall x = X0
+    quad(_grid_quad((X1, Y0, Z0), (0, 0, Z1 - Z0), (0, Y1, 0), n_big // 2), WALL, False)          # wall x = X1
+    quad(_grid_quad((X0, Y0, Z1), (0, Y1, 0), (X1 - X0, 0, 0), n_big // 2), WALL, False)          # wall z = Z1
+    quad(_grid_quad((-1.9, 2.48, -2.0), (0.8, 0, 0), (0, 0, 0.8), 2), LIGHT, False)               # ceiling panel, facing down
+    quad(_grid_quad((-2.6, 0.005, -1.6), (0, 0, 1.4), (1.8, 0, 0), 4 * detail), RUG)
+    quad(_grid_quad((X0 + 0.01, 1.1, -2.2), (0, 0.9, 0), (0, 0, 1.2), 2 * detail), PAINT)         # picture on wall x = X0
+    quad(_grid_quad((-2.4, 0.9, Z0 + 0.01), (1.6, 0, 0), (0, 1.2, 0), 2 * detail), MIRROR)        # glossy panel on wall z = Z0
+
+    def box(lo, hi, mat, n):
+        add(*_grid_box(lo, hi, n), mat)
+
+    box((-3.5, 0.0, -3.4), (-1.7, 0.55, -2.6), TUB, 6 * detail)                                            # tub
+    box((-0.9, 0.0, -3.4), (0.6, 0.8, -2.9), WOOD, 4 * detail)                                             # vanity (untextured faces: no uvs)
+    box((-0.9, 0.8, -3.4), (0.6, 0.84, -2.9), MARB, 2 * detail)
+    lvl = 4 if detail >= 4 else 2
+    for c, r, m in (((-0.5, 0.84 + 0.09, -3.15), 0.09, SSMOOTH), ((0.1, 0.84 + 0.07, -3.1), 0.07, SROUGH), ((-2.6, 0.55 + 0.12, -3.0), 0.12, SSMOOTH),
+                    ((-1.2, 0.15, -1.0), 0.15, SROUGH), ((-3.2, 0.2, 0.2), 0.2, TUB)):
+        add(*_icosphere(c, r, lvl), m)
+    box((-3.55, 0.0, -0.6), (-3.45, 1.8, -0.5), SSMOOTH, 2 * detail)                                        # towel rail posts
+    box((-3.55, 0.0, 0.3), (-3.45, 1.8, 0.4), SSMOOTH, 2 * detail)
+    cam = dict(width=width, height=height, fovy=55.0,
+               eye=tuple(float(np.float32(x)) for x in (0.0072405338287353516, 0.9124049544334412, -0.2275838851928711)),
+               lookat=tuple(float(np.float32(x)) for x in (-2.787562608718872, 0.9699121117591858, -2.6775901317596436)), up=(0.0, 1.0, 0.0))
+    return _scene("bathroom-synth", np.concatenate(V), np.concatenate(T), np.concatenate(M), [m[:4] for m in mats], [("Light", (30.0, 30.0, 30.0))],
+                  cam, uvs=np.concatenate(U), ti=np.concatenate(TI), mat_tex=[m[4] for m in mats], textures=_procedural_textures())
+

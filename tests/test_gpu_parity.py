@@ -122,7 +122,8 @@ def test_equal_distance_hits_follow_reference_order():
 
 
 @pytest.mark.parametrize("make", [lambda: synth.random_soup(1, seed=1), lambda: synth.random_soup(7, seed=2),
-                                  lambda: synth.random_soup(3000, seed=3), synth.cornell_box, lambda: synth.library_synth(detail=1)])
+                                  lambda: synth.random_soup(3000, seed=3), synth.cornell_box, lambda: synth.library_synth(detail=1),
+                                  lambda: synth.bathroom_synth(detail=1, width=96, height=96), synth.textured_room])
 def test_traversal_parity_synthetic_scenes(make):
     sd = make()
     o, g = orc.Scene(sd), api.Scene(sd)
@@ -213,7 +214,7 @@ def test_sample_ranges_add_up_and_pass_size_is_irrelevant(veach_gpu):
 
 
 @pytest.mark.parametrize("make", [synth.cornell_box, lambda: synth.grid_plane(16, 96, 80), lambda: synth.random_soup(500, seed=8, width=100, height=76),
-                                  synth.textured_room])
+                                  synth.textured_room, lambda: synth.bathroom_synth(detail=1, width=96, height=96)])
 def test_rendering_parity_synthetic_scenes(make):
     sd = make()
     o, g = orc.Scene(sd), api.Scene(sd)
