@@ -41,8 +41,8 @@ def load_workload(name):
     if name == "bathroom-synth":
         sd = synth.bathroom_synth()
         return sd, "bathroom-synth (stand-in: reference mesh not in its tree, %d tris, 5 procedural textures) 768x768" % sd.n_tris
-    if name == "library-synth":
-        sd = synth.library_synth(detail=8)
+    if name.startswith("library-synth"):   # "library-synth@D" picks the tessellation (triangles ~ D^2; the default 8 gives 1.64 M)
+        sd = synth.library_synth(detail=int(name.split("@")[1]) if "@" in name else 8)
         return sd, "library-synth (stand-in: reference mesh not in its tree, %d tris) 1280x720" % sd.n_tris
     raise SystemExit("unknown workload " + name)
 

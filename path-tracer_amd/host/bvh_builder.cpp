@@ -5,12 +5,24 @@
 // traversal visits children in a fixed order and lets the last equally-near triangle win (src/bvh.cpp:39-53,
 // src/shape.cpp:88).  Sorting uses std::sort / std::stable_partition like the reference so that ties between equal
 // centroid coordinates resolve the way the same standard library resolves them there.
+//
+// The reference builds on one thread.  Here the three initial sorts and the subtrees run on several: a subtree only
+// touches its own range of the three order arrays, and the reference's stack discipline finishes a whole subtree before
+// it starts the sibling, so a subtree's nodes form one contiguous run of indices whose internal numbering does not
+// depend on where the run starts.  Large ranges are split on the calling thread and their halves handed to tasks;
+// ranges below a cut-off are built by the sequential loop into a locally numbered array; a final sequential pass
+// replays the numbering over the small tree of large ranges and appends the local arrays with one offset each.  The
+// result is identical, node for node, to the single-threaded build (tested against the oracle's builder).
 #include "pt_host_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <future>
 #include <limits>
+#include <memory>
 #include <numeric>
+#include <thread>
 
 namespace pt_host {
 
@@ -60,24 +72,55 @@ public:
             prim_[t] = bb;
             for (int k = 0; k < 3; ++k) centroid[k][t] = ((a[k] + b[k]) + c[k]) / 3.0f;  // src/shape.cpp:44-48
         }
-        for (int axis = 0; axis < 3; ++axis) {
+        auto sort_axis = [&](int axis) {
             order_[axis].resize(n);
             std::iota(order_[axis].begin(), order_[axis].end(), uint32_t(0));
             const std::vector<float>& key = centroid[axis];
             std::sort(order_[axis].begin(), order_[axis].end(), [&key](uint32_t i, uint32_t j) { return key[i] < key[j]; });
+        };
+        if (n > kParallelCutoff) {
+            std::thread t1(sort_axis, 1), t2(sort_axis, 2);
+            sort_axis(0);
+            t1.join();
+            t2.join();
+        } else {
+            for (int axis = 0; axis < 3; ++axis) sort_axis(axis);
         }
     }
 
     void build(std::vector<pt_bvh_node>& nodes, std::vector<uint32_t>& prim_ids, uint32_t& max_depth) {
+        max_depth = 0;
+        nodes.clear();
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        if (n_ <= kParallelCutoff || hw == 1) {
+            build_range(0, n_, 1, unite(0, n_), nodes, max_depth);
+        } else {
+            budget_.store(int(hw) - 1);
+            cutoff_ = std::max<uint32_t>(kParallelCutoff / 4, n_ / (8 * hw));
+            std::unique_ptr<Top> root = build_top(0, n_, 1, unite(0, n_));
+            nodes.reserve(2 * size_t(n_));
+            nodes.push_back(pt_bvh_node{});
+            store(nodes[0], root->bounds);
+            emit(*root, 0, nodes, max_depth);
+        }
+        prim_ids = order_[0];
+        nodes.shrink_to_fit();
+    }
+
+private:
+    static constexpr uint32_t kParallelCutoff = 1u << 16;  // ranges up to this many triangles are not worth a task
+
+    // The reference's loop (src/bvh.cpp:99-166) on the range [begin, end): nodes[0] is the root of the range, children
+    // are numbered in the order the reference's stack creates them.
+    void build_range(uint32_t begin, uint32_t end, uint32_t depth, const Bounds& bounds, std::vector<pt_bvh_node>& nodes, uint32_t& max_depth) {
         struct Work {
             uint32_t node, begin, end, depth;
         };
         nodes.clear();
-        nodes.reserve(2 * size_t(n_));
+        nodes.reserve(2 * size_t(end - begin));
         nodes.push_back(pt_bvh_node{});
-        store(nodes[0], unite(0, n_));
-        std::vector<Work> todo{Work{0, 0, n_, 1}};
-        max_depth = 0;
+        store(nodes[0], bounds);
+        std::vector<Work> todo{Work{0, begin, end, depth}};
         while (!todo.empty()) {
             const Work w = todo.back();
             todo.pop_back();
@@ -105,11 +148,83 @@ public:
                 nodes[w.node].count = w.end - w.begin;
             }
         }
-        prim_ids = order_[0];
-        nodes.shrink_to_fit();
     }
 
-private:
+    // A large range: either split here (kid[0], kid[1] = the children in node-index order) or built sequentially (local).
+    struct Top {
+        uint32_t begin = 0, end = 0, depth = 0, local_depth = 0;
+        Bounds bounds;
+        bool is_split = false;
+        std::unique_ptr<Top> kid[2];
+        std::vector<pt_bvh_node> local;
+    };
+
+    std::unique_ptr<Top> build_top(uint32_t begin, uint32_t end, uint32_t depth, const Bounds& bounds) {
+        std::unique_ptr<Top> t(new Top);
+        t->begin = begin;
+        t->end = end;
+        t->depth = depth;
+        t->bounds = bounds;
+        uint32_t cut = 0;
+        if (end - begin <= cutoff_ || !split(bounds, begin, end, cut)) {
+            // small, or a leaf of more than cutoff_ triangles that the cost model refuses to split (cannot happen with
+            // MaxLeafSize 8, but the sequential loop handles it either way)
+            build_range(begin, end, depth, bounds, t->local, t->local_depth);
+            return t;
+        }
+        t->is_split = true;
+        Bounds b0 = unite(begin, cut), b1 = unite(cut, end);
+        uint32_t r0[2] = {begin, cut}, r1[2] = {cut, end};
+        if (b0.halfArea() < b1.halfArea()) {
+            std::swap(b0, b1);
+            std::swap(r0[0], r1[0]);
+            std::swap(r0[1], r1[1]);
+        }
+        std::future<std::unique_ptr<Top>> other;
+        const bool spawn = budget_.fetch_sub(1) > 0;
+        if (spawn) {
+            other = std::async(std::launch::async, [this, r1, depth, b1] {
+                std::unique_ptr<Top> k = build_top(r1[0], r1[1], depth + 1, b1);
+                budget_.fetch_add(1);
+                return k;
+            });
+        } else {
+            budget_.fetch_add(1);
+        }
+        t->kid[0] = build_top(r0[0], r0[1], depth + 1, b0);
+        t->kid[1] = spawn ? other.get() : build_top(r1[0], r1[1], depth + 1, b1);
+        return t;
+    }
+
+    // Replays the reference's numbering over the tree of large ranges; nodes[index] already holds this range's bounds.
+    void emit(const Top& t, uint32_t index, std::vector<pt_bvh_node>& nodes, uint32_t& max_depth) const {
+        max_depth = std::max(max_depth, t.depth);
+        if (!t.is_split) {
+            max_depth = std::max(max_depth, t.local_depth);
+            // local[0] is this node; local[i >= 1] lands at base + i - 1
+            const uint32_t base = uint32_t(nodes.size());
+            auto fix = [base](pt_bvh_node n) {
+                if (n.count == 0) n.first = base + n.first - 1;
+                return n;
+            };
+            nodes[index] = fix(t.local[0]);
+            nodes.resize(size_t(base) + t.local.size() - 1);
+            for (size_t i = 1; i < t.local.size(); ++i) nodes[base + i - 1] = fix(t.local[i]);
+            return;
+        }
+        const uint32_t child = uint32_t(nodes.size());
+        nodes[index].first = child;
+        nodes[index].count = 0;
+        nodes.resize(size_t(child) + 2);
+        store(nodes[child], t.kid[0]->bounds);
+        store(nodes[child + 1], t.kid[1]->bounds);
+        // the reference pushes the bigger range first, so the smaller one (kid[1] on a tie) is numbered first
+        const uint32_t s0 = t.kid[0]->end - t.kid[0]->begin, s1 = t.kid[1]->end - t.kid[1]->begin;
+        const int first = (s0 < s1) ? 0 : 1;
+        emit(*t.kid[first], child + uint32_t(first), nodes, max_depth);
+        emit(*t.kid[first ^ 1], child + uint32_t(first ^ 1), nodes, max_depth);
+    }
+
     static void store(pt_bvh_node& n, const Bounds& b) {
         for (int k = 0; k < 3; ++k) {
             n.lo[k] = b.lo[k];
@@ -190,6 +305,8 @@ private:
     }
 
     uint32_t n_;
+    uint32_t cutoff_ = 0;
+    std::atomic<int> budget_{0};
     std::vector<Bounds> prim_;
     std::vector<uint8_t> mark_;
     std::vector<float> suffix_;

@@ -145,8 +145,10 @@ def build_bvh(verts, vi):
     n_nodes, depth = C.c_uint32(), C.c_uint32()
     _chk_host(L.pt_host_build_bvh(_p(verts, c_f32p), len(verts), _p(vi, c_u32p), len(vi), C.byref(nodes_p), C.byref(n_nodes),
                                   C.byref(ids_p), C.byref(depth)))
-    nodes = np.frombuffer(C.string_at(nodes_p, n_nodes.value * C.sizeof(BvhNode)), NODE_DTYPE).copy()
-    ids = np.frombuffer(C.string_at(ids_p, len(vi) * 4), np.uint32).copy()
+    # through uint32 views: a byte-string copy is limited to 2 GiB, 50 M triangles make 3 GB of nodes
+    words = np.ctypeslib.as_array(C.cast(nodes_p, c_u32p), shape=(n_nodes.value * (C.sizeof(BvhNode) // 4),))
+    nodes = words.copy().view(NODE_DTYPE)
+    ids = np.ctypeslib.as_array(ids_p, shape=(len(vi),)).copy()
     L.pt_host_free(nodes_p)
     L.pt_host_free(ids_p)
     return nodes, ids, depth.value

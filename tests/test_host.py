@@ -37,6 +37,15 @@ def test_bvh_identical_to_oracle_synthetic(make):
     _same_bvh(make())
 
 
+def test_parallel_build_numbers_nodes_like_the_sequential_reference_order():
+    """Above 65536 triangles the host builder splits large ranges on the calling thread, builds the subtrees in tasks and
+    replays the reference's node numbering afterwards: the result must still be the oracle's (single-threaded) tree."""
+    sd = synth.library_synth(detail=4)
+    assert sd.n_tris > 4 * 65536
+    _same_bvh(sd)
+    _same_bvh(synth.random_soup(150000, seed=12))
+
+
 def test_bvh_many_identical_triangles_uses_median_fallback():
     """20 triangles collapsed to one point: every box has zero area, so no split costs less than a leaf and more than
     8 primitives force the median split on axis 0 (src/bvh.cpp:176-184)."""
