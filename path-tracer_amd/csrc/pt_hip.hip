@@ -887,6 +887,10 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         spp_pass = uint32_t(std::max<uint64_t>(1, slots / slots_per_sample));
     }
     spp_pass = std::min(spp_pass, total_spp);
+    if (p.samples_per_pass == 0) {  // automatic: passes of equal size instead of full ones and a small remainder
+        const uint32_t n_pass = (total_spp + spp_pass - 1) / spp_pass;
+        spp_pass = (total_spp + n_pass - 1) / n_pass;
+    }
     if (slots_per_sample * spp_pass > 0x7fffffffull) return fail(PT_ERR_LIMIT, "samples_per_pass too large for this resolution");
     if (spp_pass > 0xffffu) return fail(PT_ERR_LIMIT, "samples_per_pass must be < 65536");
     if (int rc = ws_reserve(s->ws, uint32_t(slots_per_sample * spp_pass), spp_pass)) return rc;
