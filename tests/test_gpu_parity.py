@@ -224,6 +224,13 @@ def test_rendering_parity_synthetic_scenes(make):
     assert helpers.rel_mse(api.film_to_image(film), orc.film_to_image(want)) < 1e-4
     assert np.allclose(film[..., 3], want[..., 3], rtol=1e-5, atol=1e-6)
     assert abs(st["closest_rays"] - ost["closest_rays"]) <= 2e-3 * ost["closest_rays"] + 2
+    # the ordered mode returns the same hit for every ray, so every path takes the same course: identical ray counts, and a
+    # film that differs only by the order of float additions (this also covers the deferred-ray hand-off between workgroups)
+    fast, fst = g.render(0, spp, traversal=api.TRAVERSE_FAST)
+    assert (fst["closest_rays"], fst["any_rays"]) == (st["closest_rays"], st["any_rays"])
+    assert np.allclose(fast, film, rtol=1e-4, atol=1e-5)
+    small, sst = g.render(0, spp, traversal=api.TRAVERSE_FAST, samples_per_pass=3)
+    assert (sst["closest_rays"], sst["any_rays"]) == (st["closest_rays"], st["any_rays"])
     g.close()
 
 
@@ -341,6 +348,9 @@ def test_full_size_library_workload_properties():
     c, sc = g.render(0, 3, traversal=api.TRAVERSE_FAST)
     assert sa["closest_rays"] + sb["closest_rays"] == sc["closest_rays"] and sa["any_rays"] + sb["any_rays"] == sc["any_rays"]
     assert np.allclose(a + b, c, rtol=1e-5, atol=1e-5)
+    e, se = g.render(0, 3, traversal=api.TRAVERSE_EXACT)
+    assert (se["closest_rays"], se["any_rays"]) == (sc["closest_rays"], sc["any_rays"])      # same hits, same paths
+    assert np.allclose(e, c, rtol=1e-4, atol=1e-5)
     want, ost = o.render(0, 1, nthreads=16)
     assert helpers.rel_mse(api.film_to_image(a), orc.film_to_image(want)) < 1e-4
     assert abs(sa["closest_rays"] - ost["closest_rays"]) <= 1e-4 * ost["closest_rays"]
