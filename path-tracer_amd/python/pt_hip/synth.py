@@ -75,6 +75,18 @@ def cornell_box(width=768, height=768):
     return _scene("cornell-box-synth", m.v, m.t, m.m, mats, [("Light", (34.0, 24.0, 8.0))], cam)
 
 
+def furnace(rho=0.5, width=48, height=48):
+    """A closed cube whose walls all emit radiance 1 and reflect diffusely with albedo rho, seen from inside.  Every path
+    vertex is an emitter, so the radiance along any ray is the geometric series 1 + rho + rho^2 + ... (cut at the
+    integrator's 32 bounces): an analytic answer for the whole MIS estimator."""
+    m = _Mesh()
+    m.box((-1, -1, -1), (1, 1, 1), 0)
+    tris = [(a, c, b) for a, b, c in m.t]           # wound so that the geometric normals face inwards
+    mats = [("emit", (rho, rho, rho), (0, 0, 0), 1.0)]
+    cam = dict(width=width, height=height, fovy=70.0, eye=(0.1, 0.2, -0.3), lookat=(0.3, 0.1, 1.0), up=(0.0, 1.0, 0.0))
+    return _scene("furnace", m.v, tris, m.m, mats, [("emit", (1.0, 1.0, 1.0))], cam)
+
+
 def random_soup(n_tris, seed=0, width=64, height=48, extent=4.0, size=0.6, n_lights=4, glossy=True):
     """Random triangle soup in a cube, a few emissive triangles, a camera looking at it.  For unit and parity tests."""
     rng = np.random.default_rng(seed)

@@ -255,6 +255,18 @@ def test_textured_materials_and_vertex_normals_match_oracle():
     g.close()
 
 
+@pytest.mark.parametrize("rho", [0.5, 0.8])
+def test_furnace_radiance_is_the_geometric_series(rho):
+    """The analytic check of the whole estimator on the GPU path: a closed, uniformly emitting diffuse enclosure returns
+    sum_{k<32} rho^k (see the oracle's test of the same name)."""
+    g = api.Scene(synth.furnace(rho))
+    film, _ = g.render(0, 64, traversal=api.TRAVERSE_FAST)
+    img = api.film_to_image(film)
+    want = (1.0 - rho ** 32) / (1.0 - rho)
+    assert abs(img.mean() - want) < 4e-3 * want
+    g.close()
+
+
 def test_work_counters_match_oracle_in_exact_mode(veach_gpu, veach_oracle):
     """Node and triangle records fetched by the reference-order traversal are the oracle's counts for primary rays."""
     film, st = veach_gpu.render(0, 1, integrator=api.INTEGRATOR_ALBEDO, traversal=api.TRAVERSE_EXACT, flags=api.FLAG_COUNT_WORK)

@@ -329,3 +329,17 @@ def test_texture_lookup_against_numpy_restatement():
             assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (px, py, prim, got, want)
             checked += 1
     assert checked > 50
+
+
+@pytest.mark.parametrize("rho", [0.5, 0.8])
+def test_furnace_radiance_is_the_geometric_series(rho):
+    """Independent of any reference output: in a closed, uniformly emitting diffuse enclosure the MIS path tracer
+    (src/integrator.cpp:45-141: emission with power-heuristic weights, light sampling, cosine sampling, Russian roulette)
+    must return sum_{k<32} rho^k for every pixel in expectation.  Catches any error in a pdf, a weight or a cosine."""
+    from pt_hip import synth
+    o = orc.Scene(synth.furnace(rho))
+    film, _ = o.render(0, 64, nthreads=8)
+    img = orc.film_to_image(film)
+    want = (1.0 - rho ** 32) / (1.0 - rho)
+    assert abs(img.mean() - want) < 4e-3 * want
+    assert np.abs(img.mean(axis=(0, 1)) - want).max() < 6e-3 * want
