@@ -41,9 +41,13 @@ def load_workload(name):
     if name == "bathroom-synth":
         sd = synth.bathroom_synth()
         return sd, "bathroom-synth (stand-in: reference mesh not in its tree, %d tris, 5 procedural textures) 768x768" % sd.n_tris
-    if name.startswith("library-synth"):   # "library-synth@D" picks the tessellation (triangles ~ D^2; the default 8 gives 1.64 M)
-        sd = synth.library_synth(detail=int(name.split("@")[1]) if "@" in name else 8)
-        return sd, "library-synth (stand-in: reference mesh not in its tree, %d tris) 1280x720" % sd.n_tris
+    if name.startswith("library-synth"):
+        # "library-synth@D" picks the tessellation (triangles ~ D^2; the default 8 gives 1.64 M, 44 gives 49 M);
+        # "library-synth@D:WxH" also the frame size (default 1280x720; 3840x2160 switches the sampler to its 4096 grid)
+        spec, _, res = (name.split("@")[1] if "@" in name else "8").partition(":")
+        w, h = (int(v) for v in res.split("x")) if res else (1280, 720)
+        sd = synth.library_synth(detail=int(spec), width=w, height=h)
+        return sd, "library-synth (stand-in: reference mesh not in its tree, %d tris) %dx%d" % (sd.n_tris, w, h)
     raise SystemExit("unknown workload " + name)
 
 

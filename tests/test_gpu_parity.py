@@ -255,6 +255,33 @@ def test_textured_materials_and_vertex_normals_match_oracle():
     g.close()
 
 
+def test_ultra_hd_frame_uses_the_4096_wide_sobol_grid():
+    """3840x2160 needs the 2^12 pixel grid of SobolSampler (scale = roundUpPow2(max(W, H)), src/sampler.cpp:89-100): Sobol'
+    values and film positions bit-exact, per-sample radiance and a one-sample AOV film against the oracle."""
+    sd = synth.cornell_box(3840, 2160)
+    o, g = orc.Scene(sd), api.Scene(sd)
+    rng = np.random.default_rng(12)
+    n = 3000
+    pix = np.stack([rng.integers(0, sd.width, n), rng.integers(0, sd.height, n)], 1).astype(np.int32)
+    pix[:4] = [[0, 0], [3839, 2159], [3839, 0], [2048, 2047]]
+    smp = rng.integers(0, 4096, n).astype(np.uint32)
+    dim = rng.integers(0, 1024, n).astype(np.uint32)
+    want = np.array([orc.sobol_sample(orc.sobol_index(12, int(s), int(p[0]), int(p[1])), int(d)) for p, s, d in zip(pix, smp, dim)], np.float32)
+    assert np.array_equal(g.sobol(pix, smp, dim).view(np.uint32), want.view(np.uint32))
+    got, ps, _ = g.li(pix, smp)
+    want_ps = np.array([o.pixel_sample(int(p[0]), int(p[1]), int(s)) for p, s in zip(pix[:400], smp[:400])])
+    assert np.array_equal(ps[:400].view(np.uint32), want_ps.view(np.uint32))
+    assert (np.floor(ps) == pix).all()
+    want_li = np.array([o.li(int(p[0]), int(p[1]), int(s))["rgb"] for p, s in zip(pix, smp)], np.float32)
+    err = np.abs(got - want_li).max(1) / (np.abs(want_li).max(1) + 1e-3)
+    assert (err < 1e-3).mean() >= 0.99
+    film, st = g.render(4000, 4001, integrator=api.INTEGRATOR_NORMAL, traversal=api.TRAVERSE_FAST)
+    want_film, ost = o.render(4000, 4001, orc.INTEGRATOR_NORMAL)
+    assert film.shape == (2164, 3844, 4) and st["closest_rays"] == ost["closest_rays"] == 3840 * 2160
+    assert np.allclose(film, want_film, rtol=1e-4, atol=2e-4)
+    g.close()
+
+
 @pytest.mark.parametrize("rho", [0.5, 0.8])
 def test_furnace_radiance_is_the_geometric_series(rho):
     """The analytic check of the whole estimator on the GPU path: a closed, uniformly emitting diffuse enclosure returns
