@@ -76,13 +76,16 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("PT_BENCH_WORKLOAD", "library-synth"))
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU")
     ap.add_argument("--traversal", choices=["exact", "fast"], default="fast")
+    ap.add_argument("--split", choices=["spp", "tile"], default="spp",
+                    help="multi-GPU partition: spp = every rank renders --spp further samples of all pixels (weak scaling, the default); "
+                         "tile = the ranks share the 32x32 pixel blocks of one frame of --spp samples (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from pt_hip import api
-    from pt_hip.dist import reduce_film, spp_range_weak
+    from pt_hip.dist import block_share, reduce_film, spp_range_weak
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -97,10 +100,12 @@ def main():
     scene = api.Scene(sd, device=local_rank)
     film = torch.empty((sd.height + 4, sd.width + 4, 4), dtype=torch.float32, device="cuda:%d" % local_rank)
     mode = api.TRAVERSE_EXACT if a.traversal == "exact" else api.TRAVERSE_FAST
-    s0, s1 = spp_range_weak(rank, a.spp)
+    tiles = a.split == "tile" and world > 1
+    s0, s1 = (0, a.spp) if tiles else spp_range_weak(rank, a.spp)
+    share = block_share(rank, world) if tiles else (0, 0)
 
     def step():
-        st = scene.render_device(film.data_ptr(), s0, s1, traversal=mode)
+        st = scene.render_device(film.data_ptr(), s0, s1, traversal=mode, block=share)
         reduce_film(film, dst=0)
         return st
 
@@ -156,10 +161,11 @@ def main():
             pass
         out = {
             "metric": "Mrays/s", "value": rays_total / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if tiles else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if "synth" in a.workload else "reference mesh, no textures",
-            "config": {"workload": label, "integrator": "MIS path tracer, 32 bounces, Sobol'", "spp_per_gpu": a.spp,
-                       "traversal": a.traversal, "parallelism": "spp-range x%d + 1 film reduce" % world},
+            "config": {"workload": label, "integrator": "MIS path tracer, 32 bounces, Sobol'",
+                       "spp_per_frame" if tiles else "spp_per_gpu": a.spp, "traversal": a.traversal,
+                       "parallelism": ("32x32-block split x%d + 1 film reduce" if tiles else "spp-range x%d + 1 film reduce") % world},
             "samples_per_s": paths_total / dt,
             "rays_per_path": rays_total / max(paths_total, 1.0),
             "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},

@@ -133,7 +133,13 @@ typedef struct pt_render_params {
     int32_t  traversal;        /* PT_TRAVERSE_* */
     uint32_t samples_per_pass; /* samples of every pixel in flight at once; 0 = automatic (up to 128 M paths, 27 GB of queues) */
     uint32_t flags;            /* PT_FLAG_* */
-    uint32_t reserved;
+    /* Image split across processes: with block_count > 1 the call renders only the 32x32 pixel blocks (the unit of the
+     * reference's BlockGenerator, include/pt/block.h:17, src/block.cpp:116-158) whose column + row index is congruent
+     * to block_rank modulo block_count; their splats still reach the 2-pixel rim of neighbouring blocks, so the films
+     * of all ranks add up to the whole frame exactly as the reference's block images do (src/block.cpp:102-110).
+     * 0 or 1 = the whole image. */
+    uint16_t block_rank;
+    uint16_t block_count;
 } pt_render_params;
 
 #define PT_FLAG_NO_KERNEL_TIMING 1u /* do not bracket kernels with HIP events (pt_stats.kernel_ms stays 0) */

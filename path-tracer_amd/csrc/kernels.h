@@ -98,6 +98,10 @@ struct PassArgs {
     uint32_t spp_pass;          // samples per pixel in this pass
     uint32_t tiles_x, tiles_y;
     uint32_t n_slots;
+    // image split: the tiles this process renders (slot order) and each tile's position in that list (-1 = not ours);
+    // null = all tiles in row-major order
+    const uint32_t* tile_list;
+    const int32_t* tile_pos;
     int32_t integrator;
     int32_t traversal;
     uint32_t max_bounce;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
         } else {
             const uint32_t lane = slot & 63u, ws = slot >> 6;
             frame = ws % pa.spp_pass;
-            const uint32_t tile = ws / pa.spp_pass;
+            const uint32_t tile = pa.tile_list ? pa.tile_list[ws / pa.spp_pass] : ws / pa.spp_pass;
             px = (tile % pa.tiles_x) * 8u + (lane & 7u);
             py = (tile / pa.tiles_x) * 8u + (lane >> 3);
         }
@@ -269,7 +273,8 @@ struct GenerateIo {
     struct Carry {
         uint32_t pix, frame;
     };
-    PTD uint32_t count(uint32_t shard) const { return min(kShard, pa.n_slots - shard * kShard); }
+    // a pass smaller than the one the workspace was laid out for leaves the last shards empty
+    PTD uint32_t count(uint32_t shard) const { return shard * kShard < pa.n_slots ? min(kShard, pa.n_slots - shard * kShard) : 0u; }
     PTD bool load(const DevScene& sc, uint32_t shard, uint32_t j, RayD& ray, Carry& c) const {
         const uint32_t slot = shard * kShard + j;
         uint32_t px, py, frame;
@@ -280,7 +285,7 @@ struct GenerateIo {
         } else {
             const uint32_t lane = slot & 63u, ws = slot >> 6;
             frame = ws % pa.spp_pass;
-            const uint32_t tile = ws / pa.spp_pass;
+            const uint32_t tile = pa.tile_list ? pa.tile_list[ws / pa.spp_pass] : ws / pa.spp_pass;
             px = (tile % pa.tiles_x) * 8u + (lane & 7u);
             py = (tile / pa.tiles_x) * 8u + (lane >> 3);
         }
@@ -853,8 +858,12 @@ __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const fl
     const uint32_t sub = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t tx = 2u * rx + (sub & 1u), ty = 2u * ry + (sub >> 1);
     const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
-    const bool inside = tx < pa.tiles_x && ty < pa.tiles_y && px < sc.cam.width && py < sc.cam.height;
-    const uint32_t tile = ty * pa.tiles_x + tx;
+    const bool in_image = tx < pa.tiles_x && ty < pa.tiles_y;
+    // a region lies inside one 32x32 block, so either all of its tiles are rendered by this process or none
+    const int32_t pos = !in_image ? -1 : (pa.tile_pos ? pa.tile_pos[ty * pa.tiles_x + tx] : int32_t(ty * pa.tiles_x + tx));
+    if (__syncthreads_or(pos >= 0) == 0) return;
+    const bool inside = pos >= 0 && px < sc.cam.width && py < sc.cam.height;
+    const uint32_t tile = uint32_t(pos);
     // source pixel index inside the region: (sx, sy) in [0,16)^2
     const int sxp = int(px - 16u * rx), syp = int(py - 16u * ry);
     const int bx = int(px & ~31u), by = int(py & ~31u);

@@ -121,6 +121,11 @@ struct pt_hip_scene {
     EventPool events;
     uint32_t* batch_fetch = nullptr;  // per-shard fetch counters of the batched ordered queries
     size_t batch_fetch_cap = 0;
+    // image split (pt_render_params::block_count > 1): tile tables of the most recent (rank, count)
+    uint32_t* tile_list = nullptr;
+    int32_t* tile_pos = nullptr;
+    uint32_t split_key = 0, split_tiles = 0;
+    uint64_t split_pixels = 0;
 };
 
 namespace {
@@ -702,6 +707,45 @@ int normalise(const pt_render_params* in, pt_render_params& p) {
     if (p.spp_end <= p.spp_begin) return fail(PT_ERR_INVALID, "empty sample range");
     if (p.integrator < 0 || p.integrator > 2) return fail(PT_ERR_INVALID, "unknown integrator");
     if (p.traversal < 0 || p.traversal > 1) return fail(PT_ERR_INVALID, "unknown traversal mode");
+    if (p.block_count > 1 && p.block_rank >= p.block_count) return fail(PT_ERR_INVALID, "block_rank must be below block_count");
+    return PT_OK;
+}
+
+// Tile tables of an image split: the 8x8 tiles of the 32x32 blocks with (column + row) % count == rank, block after
+// block, and the inverse table.  Kept until a call asks for another (rank, count).
+int prepare_split(pt_hip_scene* s, uint32_t rank, uint32_t count, uint32_t tiles_x, uint32_t tiles_y) {
+    const uint32_t key = (count << 16) | rank;
+    if (s->split_key == key) return PT_OK;
+    const size_t n_tiles = size_t(tiles_x) * tiles_y;
+    if (!s->tile_list) {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, n_tiles * sizeof(uint32_t)));
+        s->owned.push_back(d);
+        s->tile_list = static_cast<uint32_t*>(d);
+        HIP_TRY(hipMalloc(&d, n_tiles * sizeof(int32_t)));
+        s->owned.push_back(d);
+        s->tile_pos = static_cast<int32_t*>(d);
+    }
+    std::vector<uint32_t> list;
+    std::vector<int32_t> pos(n_tiles, -1);
+    uint64_t pixels = 0;
+    const uint32_t blocks_x = (tiles_x + 3) / 4, blocks_y = (tiles_y + 3) / 4;
+    for (uint32_t by = 0; by < blocks_y; ++by)
+        for (uint32_t bx = 0; bx < blocks_x; ++bx) {
+            if ((bx + by) % count != rank) continue;
+            for (uint32_t ty = 4 * by; ty < std::min(4 * by + 4, tiles_y); ++ty)
+                for (uint32_t tx = 4 * bx; tx < std::min(4 * bx + 4, tiles_x); ++tx) {
+                    pos[size_t(ty) * tiles_x + tx] = int32_t(list.size());
+                    list.push_back(ty * tiles_x + tx);
+                    pixels += uint64_t(std::min(8u, s->width - 8 * tx)) * std::min(8u, s->height - 8 * ty);
+                }
+        }
+    HIP_TRY(hipStreamSynchronize(g_stream));  // an earlier call's kernels may still read the tables
+    if (!list.empty()) HIP_TRY(hipMemcpy(s->tile_list, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->tile_pos, pos.data(), n_tiles * sizeof(int32_t), hipMemcpyHostToDevice));
+    s->split_key = key;
+    s->split_tiles = uint32_t(list.size());
+    s->split_pixels = pixels;
     return PT_OK;
 }
 
@@ -869,8 +913,17 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
     if (st) std::memset(st, 0, sizeof(*st));
     const uint32_t W = s->width, H = s->height;
     const uint32_t tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
-    const uint64_t slots_per_sample = uint64_t(tiles_x) * tiles_y * 64;
+    const bool split = p.block_count > 1;
+    if (split)
+        if (int rc = prepare_split(s, p.block_rank, p.block_count, tiles_x, tiles_y)) return rc;
+    const uint64_t slots_per_sample = uint64_t(split ? s->split_tiles : tiles_x * tiles_y) * 64;
+    const uint64_t pixels = split ? s->split_pixels : uint64_t(W) * H;
     const uint32_t total_spp = p.spp_end - p.spp_begin;
+    if (slots_per_sample == 0) {  // more ranks than blocks: nothing of this image is ours
+        HIP_TRY(hipMemsetAsync(d_film, 0, sizeof(float) * 4 * size_t(W + 4) * size_t(H + 4), g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        return PT_OK;
+    }
     uint32_t spp_pass = p.samples_per_pass;
     if (spp_pass == 0) {
         // Automatic: as many samples per pixel in flight as fit kAutoSlots path slots (224 B of queue space each).  Every
@@ -913,13 +966,15 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         pa.tiles_x = tiles_x;
         pa.tiles_y = tiles_y;
         pa.n_slots = uint32_t(slots_per_sample * nf);
+        pa.tile_list = split ? s->tile_list : nullptr;
+        pa.tile_pos = split ? s->tile_pos : nullptr;
         pa.integrator = p.integrator;
         pa.traversal = p.traversal;
         pa.max_bounce = p.max_bounce;
         if (int rc = launch_generate(s, pa, tm, count)) return rc;
         if (st) {
-            st->paths += uint64_t(W) * H * nf;
-            st->closest_rays += uint64_t(W) * H * nf;
+            st->paths += pixels * nf;
+            st->closest_rays += pixels * nf;
         }
         if (int rc = run_bounces(s, pa, st, tm, count)) return rc;
         if (int rc = tm.begin(PT_K_FILM)) return rc;

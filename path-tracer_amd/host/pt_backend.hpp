@@ -167,12 +167,16 @@ struct Film {
     }
 };
 
-// render() of src/main.cpp:76-98 for sample numbers [spp_begin, spp_end): adds into `result`.
-inline pt_stats render(Accel* accel, const Integrator* integrator, uint32_t spp_begin, uint32_t spp_end, Film* result) {
+// render() of src/main.cpp:76-98 for sample numbers [spp_begin, spp_end): adds into `result`.  With block_count > 1
+// only this rank's share of the 32x32 pixel blocks is rendered (pt_render_params::block_rank / block_count).
+inline pt_stats render(Accel* accel, const Integrator* integrator, uint32_t spp_begin, uint32_t spp_end, Film* result,
+                       uint32_t block_rank = 0, uint32_t block_count = 0) {
     pt_render_params p{};
     p.spp_begin = spp_begin;
     p.spp_end = spp_end;
     p.max_bounce = 32;
+    p.block_rank = uint16_t(block_rank);
+    p.block_count = uint16_t(block_count);
     p.integrator = integrator->kind();
     p.traversal = accel->traversal();
     Film part(result->width, result->height);

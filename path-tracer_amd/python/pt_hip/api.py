@@ -51,7 +51,8 @@ class SceneDesc(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [("spp_begin", C.c_uint32), ("spp_end", C.c_uint32), ("max_bounce", C.c_uint32), ("integrator", C.c_int32),
-                ("traversal", C.c_int32), ("samples_per_pass", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("traversal", C.c_int32), ("samples_per_pass", C.c_uint32), ("flags", C.c_uint32), ("block_rank", C.c_uint16),
+                ("block_count", C.c_uint16)]
 
 
 class Stats(C.Structure):
@@ -261,10 +262,13 @@ class Scene:
         _chk(hip_lib().pt_hip_occluded(self.h, rays.ctypes.data, len(rays), _p(occ, c_u8p), _p(first, c_i32p), mode))
         return occ, first
 
-    def params(self, spp_begin, spp_end, integrator=INTEGRATOR_PATH, traversal=TRAVERSE_EXACT, samples_per_pass=0, max_bounce=32, flags=0):
+    def params(self, spp_begin, spp_end, integrator=INTEGRATOR_PATH, traversal=TRAVERSE_EXACT, samples_per_pass=0, max_bounce=32, flags=0,
+               block=(0, 0)):
+        """block = (rank, count): render only this rank's share of the 32x32 pixel blocks (see pt_render_params)."""
         p = RenderParams()
         p.spp_begin, p.spp_end, p.max_bounce = spp_begin, spp_end, max_bounce
         p.integrator, p.traversal, p.samples_per_pass, p.flags = integrator, traversal, samples_per_pass, flags
+        p.block_rank, p.block_count = block
         return p
 
     def render(self, spp_begin, spp_end, **kw):

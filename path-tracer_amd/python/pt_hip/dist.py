@@ -1,10 +1,22 @@
-"""Multi-GPU sharding of one frame: every rank renders a disjoint range of Sobol' sample indices into its own film and
-the films are summed with one reduce (the reference's only reduction is ImageBlock::put(ImageBlock&), src/block.cpp:102-110).
+"""Multi-GPU sharding of one frame: every rank renders a disjoint part of the (pixel, sample number) grid into its own
+film and the films are summed with one reduce (the reference's only reduction is ImageBlock::put(ImageBlock&),
+src/block.cpp:102-110).  Two partitions: by range of Sobol' sample numbers (every rank sees all pixels), or by 32x32
+pixel blocks, the unit of the reference's BlockGenerator (every rank runs all sample numbers on its blocks).
 
 The Sobol' index is a pure function of (pixel, sample number) (src/sampler.cpp:96-100), so ranks need no coordination
-beyond agreeing on the ranges.  The weight channel is summed too; rgb / weight is taken once after the reduce
+beyond agreeing on the partition.  The weight channel is summed too; rgb / weight is taken once after the reduce
 (include/pt/color.h:135-140).
 """
+
+
+def block_owner(bx, by, world):
+    """Rank that renders block (column bx, row by) under the block partition: diagonal stripes."""
+    return (bx + by) % world
+
+
+def block_share(rank, world):
+    """The `block` argument of Scene.render / render_device for this rank (whole image when there is one rank)."""
+    return (rank, world) if world > 1 else (0, 0)
 
 
 def spp_range_weak(rank, spp_per_rank):

@@ -24,6 +24,17 @@ def test_ranges_partition_the_frame():
         assert r[0] == (0, 16) and all(a[1] == b[0] for a, b in zip(r, r[1:])) and r[-1][1] == 16 * world
 
 
+def test_block_partition_covers_every_block_once_and_evenly():
+    """Diagonal stripes of 32x32 blocks: each block has one owner, and the shares differ by less than one block row."""
+    for world in (1, 2, 3, 4, 8):
+        for nbx, nby in ((40, 23), (24, 24), (120, 68), (3, 2)):
+            owners = np.array([[ptdist.block_owner(bx, by, world) for bx in range(nbx)] for by in range(nby)])
+            counts = np.bincount(owners.ravel(), minlength=world)
+            assert counts.sum() == nbx * nby and owners.min() >= 0 and owners.max() < world
+            assert counts.max() - counts.min() <= max(nbx, nby)
+        assert ptdist.block_share(0, 1) == (0, 0) and ptdist.block_share(2, 4) == (2, 4)
+
+
 def _worker(rank, world, port, out_path):
     for p in (os.path.join(ROOT, "path-tracer_amd", "python"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)

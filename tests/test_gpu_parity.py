@@ -213,6 +213,34 @@ def test_sample_ranges_add_up_and_pass_size_is_irrelevant(veach_gpu):
     assert np.allclose(a + b, c, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("world", [2, 3, 7])
+def test_block_shares_add_up_to_the_whole_frame(world):
+    """Image split by 32x32 pixel blocks (the reference's BlockGenerator unit): the films of all ranks sum to the
+    unsplit film, every path is rendered by exactly one rank, and a rank's film is empty away from its own blocks."""
+    from pt_hip.dist import block_owner
+    sd = synth.cornell_box(200, 136)             # 7 x 5 blocks, the last column and row partial
+    g = api.Scene(sd)
+    whole, wst = g.render(0, 6, traversal=api.TRAVERSE_FAST)
+    total = np.zeros_like(whole)
+    paths = rays = 0
+    for rank in range(world):
+        film, st = g.render(0, 6, traversal=api.TRAVERSE_FAST, block=(rank, world), samples_per_pass=4)
+        total += film
+        paths += st["paths"]
+        rays += st["closest_rays"] + st["any_rays"]
+        for by in range(5):
+            for bx in range(7):
+                if block_owner(bx, by, world) != rank and all(block_owner(bx + dx, by + dy, world) != rank
+                                                              for dx in (-1, 0, 1) for dy in (-1, 0, 1)):
+                    assert not film[2 + 32 * by:2 + 32 * by + 32, 2 + 32 * bx:2 + 32 * bx + 32].any()
+    assert paths == wst["paths"] == 200 * 136 * 6
+    assert rays == wst["closest_rays"] + wst["any_rays"]
+    assert np.allclose(total, whole, rtol=1e-5, atol=1e-5)
+    with pytest.raises(api.PtError):
+        g.render(0, 1, block=(2, 2))
+    g.close()
+
+
 @pytest.mark.parametrize("make", [synth.cornell_box, lambda: synth.grid_plane(16, 96, 80), lambda: synth.random_soup(500, seed=8, width=100, height=76),
                                   synth.textured_room, lambda: synth.bathroom_synth(detail=1, width=96, height=96)])
 def test_rendering_parity_synthetic_scenes(make):

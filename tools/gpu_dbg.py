@@ -1,21 +1,27 @@
-import sys, time
-sys.path[:0]=['path-tracer_amd/python','oracle','tests']
+"""Scratch: image split debugging."""
+import sys
+sys.path[:0] = ['path-tracer_amd/python', 'oracle', 'tests']
 import numpy as np
 from pt_hip import api, synth
-import orc, helpers
-t=time.time(); sd=synth.library_synth(detail=int(sys.argv[1]) if len(sys.argv)>1 else 4); print('gen',time.time()-t,'tris',sd.n_tris, flush=True)
-t=time.time(); g=api.Scene(sd); print('gpu scene',time.time()-t,'depth',g.host.depth,'nodes',len(g.host.nodes), flush=True)
-t=time.time(); o=orc.Scene(sd); print('oracle scene',time.time()-t, flush=True)
-for mode in (0,1):
-    film,st=g.render(0,8,traversal=mode,flags=api.FLAG_COUNT_WORK)
-    r={'generate':st['paths'],'extend':st['closest_rays']-st['paths'],'shadow':st['any_rays']}
-    print('mode',mode,'sec',round(st['seconds'],4),'rays/path',(st['closest_rays']+st['any_rays'])/st['paths'],{k:(round(st['nodes_fetched'][k]/max(r[k],1),2),round(st['tris_fetched'][k]/max(r[k],1),2)) for k in r}, 'retraces',st['exact_retraces'], {k:round(v,2) for k,v in st['kernel_ms'].items()}, st['kernel_launches'], flush=True)
-    film2,st2=g.render(0,8,traversal=mode)
-    print('   uninstrumented sec',round(st2['seconds'],4), {k:round(v,2) for k,v in st2['kernel_ms'].items()}, 'Mrays/s', (st2['closest_rays']+st2['any_rays'])/st2['seconds']/1e6, flush=True)
-    if mode==0: f0=film2
-    else: print('   exact vs fast film max diff', np.abs(film2-f0).max(), 'rays', st2['closest_rays'], flush=True)
-t=time.time(); of,ost=o.render(0,2,nthreads=16); print('oracle 2spp',time.time()-t, ost, flush=True)
-gf,gst=g.render(0,2,traversal=0)
-print('relmse', helpers.rel_mse(api.film_to_image(gf), orc.film_to_image(of)), gst['closest_rays'], ost['closest_rays'], gst['any_rays'], ost['any_rays'])
-img=api.film_to_image(film2); print('mean',img.mean(), 'nan', np.isnan(img).sum())
-np.save('gpurun_out/library8.npy', img.astype(np.float16))
+sd = synth.cornell_box(200, 136)
+g = api.Scene(sd)
+for spp_pass in (0, 4):
+    whole, wst = g.render(0, 6, traversal=1, samples_per_pass=spp_pass)
+    print('whole', spp_pass, wst['paths'], wst['closest_rays'], wst['any_rays'])
+for mode in (0, 1):
+    for world in (2,):
+        total = np.zeros_like(whole)
+        for rank in range(world):
+            film, st = g.render(0, 6, traversal=mode, block=(rank, world), samples_per_pass=4)
+            print(' mode', mode, 'rank', rank, st['paths'], st['closest_rays'], st['any_rays'])
+            total += film
+        d = np.abs(total - whole)
+        print(' max diff', d.max(), 'n diff', (d > 1e-4).sum(), 'weight diff', np.abs(total[..., 3] - whole[..., 3]).max())
+        ys, xs = np.nonzero(d.max(-1) > 1e-4)
+        print(' where', list(zip(xs[:10], ys[:10])))
+a0, st = g.render(0, 6, traversal=1, integrator=api.INTEGRATOR_ALBEDO)
+t = np.zeros_like(a0)
+for rank in range(3):
+    f, st = g.render(0, 6, traversal=1, integrator=api.INTEGRATOR_ALBEDO, block=(rank, 3))
+    t += f
+print('albedo diff', np.abs(t - a0).max())
