@@ -168,6 +168,8 @@ typedef struct pt_hip_scene pt_hip_scene;
 
 /* Selects the GPU this process drives and creates its stream.  No counterpart in the reference (CPU only). */
 int pt_hip_init(int device_ordinal);
+/* Number of GPUs visible to this process (>= 0), or a negative PT_ERR_*.  May be called before pt_hip_init. */
+int pt_hip_device_count(void);
 int pt_hip_shutdown(void);
 const char* pt_hip_last_error(void);
 int pt_hip_abi_version(void);

@@ -758,6 +758,12 @@ extern "C" {
 const char* pt_hip_last_error(void) { return g_error.c_str(); }
 int pt_hip_abi_version(void) { return PT_HIP_ABI_VERSION; }
 
+int pt_hip_device_count(void) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    return n;
+}
+
 int pt_hip_init(int device_ordinal) {
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));

@@ -305,6 +305,13 @@ class Scene:
         return out
 
 
+def device_count():
+    n = hip_lib().pt_hip_device_count()
+    if n < 0:
+        raise PtError("pt_hip error %d: %s" % (n, hip_lib().pt_hip_last_error().decode()))
+    return n
+
+
 def selftest_division(pairs, seed=1, device=0):
     init(device)
     bad = C.c_uint64(0)

@@ -371,6 +371,19 @@ def test_command_line_front_end_writes_the_same_images(tmp_path):
         got = exr_lite.read_rgb(os.path.join(str(tmp_path), stem + ".exr"))
         assert got.shape == want.shape
         assert np.allclose(got, want, rtol=1e-5, atol=1e-7), stem
+    # two worker processes (they share the one GPU of a test box), split by sample range and by 32x32 blocks
+    assert api.device_count() >= 1
+    for split in ("spp", "tile"):
+        out = tmp_path / split
+        out.mkdir()
+        r = subprocess.run([cli, "--no-gui", "-s", "4", "--gpus", "2", "--split", split, "--scenes", str(tmp_path), "--out", str(out),
+                            "cornell-box"], capture_output=True, text=True, timeout=100)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "on 2 GPUs" in r.stdout
+        for stem in ("albedo", "normal", "result"):
+            one = exr_lite.read_rgb(os.path.join(str(tmp_path), stem + ".exr"))
+            two = exr_lite.read_rgb(os.path.join(str(out), stem + ".exr"))
+            assert np.allclose(one, two, rtol=1e-4, atol=1e-6), (split, stem)
     g.close()
 
 

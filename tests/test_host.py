@@ -227,5 +227,7 @@ def test_cli_argument_errors_match_the_reference(tmp_path):
     assert r.returncode == 255 and '"--threads" argument expects a positive integer' in r.stderr
     r = subprocess.run([CLI, "--bdpt"], capture_output=True, text=True)
     assert r.returncode == 255
+    r = subprocess.run([CLI, "--split", "rows"], capture_output=True, text=True)
+    assert r.returncode == 255 and '"--split" expects spp or tile' in r.stderr
     r = subprocess.run([CLI, "--no-gui", "--scenes", str(tmp_path), "library"], capture_output=True, text=True)
     assert r.returncode == 1 and r.stderr.startswith("Error: ")
