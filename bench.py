@@ -107,6 +107,8 @@ def main():
     def step():
         st = scene.render_device(film.data_ptr(), s0, s1, traversal=mode, block=share)
         reduce_film(film, dst=0)
+        if world > 1:
+            torch.cuda.synchronize()   # the next step clears the film on the renderer's own stream: the reduce must be done with it
         return st
 
     def fence():
