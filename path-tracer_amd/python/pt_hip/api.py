@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _PKG = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
-LIB_DIR = os.path.join(_PKG, "lib")
+LIB_DIR = os.environ.get("PT_HIP_LIB_DIR") or os.path.join(_PKG, "lib")   # where libpt_hip.so and libpt_host.so are
 
 TRAVERSE_EXACT, TRAVERSE_FAST = 0, 1
 FLAG_NO_KERNEL_TIMING, FLAG_COUNT_WORK = 1, 2
