@@ -183,7 +183,9 @@ def filter_table():
 class HostScene:
     """A pt_scene_desc assembled from a SceneData through the host substrate (BVH, camera, light table)."""
 
-    def __init__(self, sd):
+    def __init__(self, sd, bvh=None):
+        """bvh = (nodes as NODE_DTYPE, prim_ids): use this tree instead of building the reference's (any binary tree in
+        the reference's node layout is a valid input of the backend; tests use it for shapes the builder never makes)."""
         self.sd = sd
         k = self.keep = {}
         k["verts"] = np.ascontiguousarray(sd.verts, np.float32)
@@ -195,7 +197,10 @@ class HostScene:
         mats["kd"], mats["ks"], mats["ns"], mats["tex"] = sd.mat_kd, sd.mat_ks, sd.mat_ns, sd.mat_tex
         k["mats"] = mats
         k["lights"], k["light_id"] = make_lights(sd)
-        self.nodes, self.prim_ids, self.depth = build_bvh(k["verts"], k["vi"])
+        if bvh is None:
+            self.nodes, self.prim_ids, self.depth = build_bvh(k["verts"], k["vi"])
+        else:
+            self.nodes, self.prim_ids, self.depth = np.ascontiguousarray(bvh[0], NODE_DTYPE), np.ascontiguousarray(bvh[1], np.uint32), None
         k["tex"] = [np.ascontiguousarray(t, np.float32) for t in sd.textures]
         texs = (Texture * max(1, len(k["tex"])))()
         for i, t in enumerate(k["tex"]):
@@ -230,9 +235,9 @@ def init(device=0):
 class Scene:
     """Device scene (pt_hip_scene) built from a SceneData."""
 
-    def __init__(self, sd, device=0):
+    def __init__(self, sd, device=0, bvh=None):
         init(device)
-        self.host = HostScene(sd)
+        self.host = HostScene(sd, bvh)
         self.sd = sd
         h = C.c_void_p()
         _chk(hip_lib().pt_hip_scene_create(C.byref(self.host.desc), C.byref(h)))

@@ -141,6 +141,48 @@ def test_traversal_parity_synthetic_scenes(make):
     g.close()
 
 
+def test_hand_made_deep_tree_runs_on_the_spilled_stack():
+    """A 46-level comb-shaped tree (helpers.comb_scene_and_tree) handed to the backend in place of the builder's: rays
+    along the spine keep up to 44 deferred subtrees on the traversal stack, well past its 24 LDS entries.  Both modes
+    must agree bit for bit on this tree; against the oracle (which builds the reference's tree over the same triangles)
+    the hits agree except where a ray grazes a box face of one of the two trees."""
+    sd, nodes, ids = helpers.comb_scene_and_tree(44)
+    g, o = api.Scene(sd, bvh=(nodes, ids)), orc.Scene(sd)
+    rng = np.random.default_rng(3)
+    n = 6000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0] = 50.0
+    rays[:, 1:3] = rng.uniform(-0.7, 0.7, (n, 2))
+    rays[:, 3] = -1.0
+    rays[:, 4:6] = rng.uniform(-0.01, 0.01, (n, 2))
+    rays[: n // 3, 0] = -6.0                         # the other way round: nothing is deferred
+    rays[: n // 3, 3] = 1.0
+    rays[:, 3:6] /= np.linalg.norm(rays[:, 3:6], axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    rays[n // 2:, 7] = rng.uniform(5.0, 60.0, n - n // 2)
+    exact, fast, want = g.intersect(rays, api.TRAVERSE_EXACT), g.intersect(rays, api.TRAVERSE_FAST), o.intersect(rays)
+    assert np.array_equal(fast.view(np.uint32), exact.view(np.uint32))
+    assert 0.3 < (want["prim"] >= 0).mean() < 0.999
+    assert helpers.hits_equal(exact, want).mean() > 0.999
+    occ_e, occ_f, occ_w = g.occluded(rays, api.TRAVERSE_EXACT)[0], g.occluded(rays, api.TRAVERSE_FAST)[0], o.occluded(rays)[0]
+    assert np.array_equal(occ_e, occ_f) and (occ_e == occ_w).mean() > 0.999
+    film, st = g.render(0, 8, traversal=api.TRAVERSE_FAST)
+    film_e, st_e = g.render(0, 8, traversal=api.TRAVERSE_EXACT)
+    want_film, _ = o.render(0, 8)
+    assert (st["closest_rays"], st["any_rays"]) == (st_e["closest_rays"], st_e["any_rays"])
+    assert helpers.rel_mse(api.film_to_image(film), orc.film_to_image(want_film)) < 1e-4
+    g.close()
+
+
+def test_tree_deeper_than_the_traversal_stack_is_refused():
+    sd, nodes, ids = helpers.comb_scene_and_tree(100)
+    with pytest.raises(api.PtError, match="deeper than the traversal stack"):
+        api.Scene(sd, bvh=(nodes, ids))
+    nodes[5]["first"] = 0                            # a child index that closes a cycle
+    with pytest.raises(api.PtError, match="node shared"):
+        api.Scene(sd, bvh=(nodes, ids))
+
+
 # ------------------------------------------------------------------------------------------------ film and AOVs
 
 @pytest.mark.parametrize("name,integ", [("normal", api.INTEGRATOR_NORMAL), ("albedo", api.INTEGRATOR_ALBEDO)])
