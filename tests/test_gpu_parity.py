@@ -141,6 +141,32 @@ def test_traversal_parity_synthetic_scenes(make):
     g.close()
 
 
+def test_astronomically_large_scene_takes_the_plain_division_path():
+    """Coordinates beyond 2^59: the products of the short division could overflow, so every ray of such a scene is routed
+    through the IEEE division form of the box test (in the follow-up kernels of the ordered mode).  Same hits as the
+    oracle, bit for bit, in both modes."""
+    sd = synth.random_soup(400, seed=21, extent=2e18, size=4e17)
+    o, g = orc.Scene(sd), api.Scene(sd)
+    rng = np.random.default_rng(5)
+    n = 20000
+    org = rng.normal(size=(n, 3))
+    org *= 6e18 / np.linalg.norm(org, axis=1, keepdims=True)
+    d = rng.uniform(-2e18, 2e18, (n, 3)) - org
+    dist = np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 3:6] = org, d / dist
+    rays[:, 7] = np.where(rng.random(n) < 0.5, np.inf, (dist[:, 0] * rng.uniform(0.5, 1.5, n)))   # camera rays would end after 10^4 units
+    want = o.intersect(rays)
+    assert 0.1 < (want["prim"] >= 0).mean() < 0.99
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_EXACT), want).all()
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_FAST), want).all()
+    occ, first = o.occluded(rays)
+    g_occ, g_first = g.occluded(rays, api.TRAVERSE_EXACT)
+    assert np.array_equal(g_occ, occ) and np.array_equal(g_first, first)
+    assert np.array_equal(g.occluded(rays, api.TRAVERSE_FAST)[0], occ)
+    g.close()
+
+
 def test_hand_made_deep_tree_runs_on_the_spilled_stack():
     """A 46-level comb-shaped tree (helpers.comb_scene_and_tree) handed to the backend in place of the builder's: rays
     along the spine keep up to 44 deferred subtrees on the traversal stack, well past its 24 LDS entries.  Both modes
