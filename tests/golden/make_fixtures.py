@@ -4,8 +4,14 @@
 Inputs  (read, never copied as-is):  <reference>/scenes/veach-mis/veach-mis.{obj,mtl,xml}  -- the one mesh the reference ships
                                      <reference>/scenes/veach-mis/{normal,albedo}.exr       -- float images written by the real
                                                                                                reference binary (32 spp Sobol')
+                                     <reference>/scenes/veach-mis/result.png                -- its path-traced image (8-bit sRGB,
+                                                                                               sample count not recorded)
 Outputs (small, committed):          tests/golden/veach_mis_scene.npz   flat indexed mesh + materials + camera + light infos
                                      tests/golden/veach_mis_aov.npz     every 4th row/column of the two float images
+                                     tests/golden/veach_mis_result.npz  means of the 8x8 pixel blocks of result.png, taken after
+                                                                        decoding its 8-bit sRGB pixels back to linear values
+                                                                        (averaging encoded values would make a noisier image
+                                                                        look darker: the encoding is concave)
 """
 import os
 import sys
@@ -32,7 +38,13 @@ def main():
     a = read_rgb(os.path.join(folder, "albedo.exr"))
     np.savez_compressed(os.path.join(HERE, "veach_mis_aov.npz"), stride=STRIDE, spp=32, normal=n[::STRIDE, ::STRIDE],
                         albedo=a[::STRIDE, ::STRIDE])
-    print("tris", sd.n_tris, "aov", n[::STRIDE, ::STRIDE].shape)
+    from PIL import Image
+    png = np.asarray(Image.open(os.path.join(folder, "result.png")).convert("RGB"), np.float64) / 255.0
+    lin = np.where(png <= 0.04045, png / 12.92, np.power((png + 0.055) / 1.055, 2.4))      # Color3f::toLinearRGB
+    h, w = lin.shape[:2]
+    blocks = lin.reshape(h // 8, 8, w // 8, 8, 3).mean((1, 3))
+    np.savez_compressed(os.path.join(HERE, "veach_mis_result.npz"), block=8, linear=blocks.astype(np.float32))
+    print("tris", sd.n_tris, "aov", n[::STRIDE, ::STRIDE].shape, "result blocks", blocks.shape)
 
 
 if __name__ == "__main__":

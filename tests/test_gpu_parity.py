@@ -272,6 +272,26 @@ def test_path_traced_image_matches_oracle(veach_gpu, veach_oracle):
     assert helpers.rel_mse(api.film_to_image(fast), ref) < 1e-5
 
 
+def test_path_traced_image_matches_reference_png(veach_gpu):
+    """The HIP path against the reference binary's own path-traced image of this scene (scenes/veach-mis/result.png, kept
+    as linear 8x8 block means in tests/golden/veach_mis_result.npz; see the oracle's test of the same name).  At 512
+    samples per pixel our own noise is negligible: the total agrees to 0.3 % (measured 0.08 %) and every brightness band
+    to 2 % (measured: within 1.2 %, most within 0.2 %); blocks are put into bands by a second render of other sample
+    numbers, so that no image under comparison chooses its own band.  Both traversal modes."""
+    from conftest import GOLDEN
+    want = np.load(os.path.join(GOLDEN, "veach_mis_result.npz"))["linear"].astype(np.float64)
+    lum = helpers.png_block_means(api.film_to_image(veach_gpu.render(6000, 6256, traversal=api.TRAVERSE_FAST)[0])).mean(-1)
+    for mode, spp in ((api.TRAVERSE_FAST, 512), (api.TRAVERSE_EXACT, 128)):
+        film, _ = veach_gpu.render(0, spp, traversal=mode)
+        got = helpers.png_block_means(api.film_to_image(film))
+        assert abs(got.sum() / want.sum() - 1.0) < 0.003
+        assert np.abs(got - want).mean() < 0.025 * want.mean()      # the reference image's own noise
+        for lo, hi in ((0.002, 0.005), (0.005, 0.01), (0.01, 0.02), (0.02, 0.05), (0.05, 0.1), (0.1, 0.2), (0.2, 0.5), (0.5, 1.01)):
+            m = (lum >= lo) & (lum < hi)
+            assert m.mean() > 0.02
+            assert abs(got[m].mean() / want[m].mean() - 1.0) < 0.02, (mode, lo, hi)
+
+
 def test_sample_ranges_add_up_and_pass_size_is_irrelevant(veach_gpu):
     """Multi-GPU sharding relies on this: films of disjoint sample ranges sum to the film of the union, and the number
     of samples kept in flight per pass does not change the result (both up to float summation order)."""

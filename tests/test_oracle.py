@@ -1,8 +1,9 @@
 """The oracle against the reference's own artefacts and against first principles.
 
 Pins: scenes/veach-mis/normal.exr and albedo.exr were written by the real reference binary (32 spp Sobol', Gaussian
-film); tests/golden/veach_mis_aov.npz holds every 4th row/column of them.  Everything else here checks the oracle's
-restated functions against closed forms or brute force.
+film); tests/golden/veach_mis_aov.npz holds every 4th row/column of them.  scenes/veach-mis/result.png is the reference's
+path-traced image of the same scene; tests/golden/veach_mis_result.npz holds its 8x8 block means (linear values).  Everything else here
+checks the oracle's restated functions against closed forms or brute force.
 """
 import os
 
@@ -51,6 +52,29 @@ def test_aov_full_image_against_reference_exr(aov_renders, name):
     assert d.mean() < 5e-6
     assert (d > 1e-5).mean() < 2e-3
     assert d.max() < 0.1
+
+
+def test_path_traced_image_matches_reference_png(veach_oracle):
+    """The whole MIS integrator against the reference binary's own output: scenes/veach-mis/result.png (8-bit sRGB, few
+    samples per pixel by its noise; tests/golden/veach_mis_result.npz keeps the means of its 8x8 pixel blocks after decoding
+    to linear values).  16 samples per pixel of the oracle go through the same encoding and decoding.  The light the two
+    images hold in total agrees to 0.5 % (measured 0.11 %), and so does every brightness band to a few per cent -- the
+    glossy plates, the floor, the wall and the light sources all cover thousands of blocks, so a wrong BRDF, pdf, MIS
+    weight or light sampling density would show in one band or another.  (Blocks are put into bands by the mean of the
+    two images, so that neither image's noise decides the band; the nearly black band is left out: truncation to 8 bits
+    makes the noisier image brighter there.)"""
+    import helpers
+    want = np.load(os.path.join(GOLDEN, "veach_mis_result.npz"))["linear"].astype(np.float64)
+    film, _ = veach_oracle.render(0, 16)
+    got = helpers.png_block_means(orc.film_to_image(film))
+    assert abs(got.sum() / want.sum() - 1.0) < 0.005
+    assert np.abs(got - want).mean() < 0.04 * want.mean()          # block by block: Monte Carlo noise of both images
+    lum = (0.5 * (got + want)).mean(-1)
+    for lo, hi, tol in ((0.002, 0.005, 0.06), (0.005, 0.01, 0.08), (0.01, 0.02, 0.03), (0.02, 0.05, 0.03), (0.05, 0.1, 0.01),
+                        (0.1, 0.2, 0.01), (0.2, 0.5, 0.01), (0.5, 1.01, 0.01)):
+        m = (lum >= lo) & (lum < hi)
+        assert m.mean() > 0.02
+        assert abs(got[m].mean() / want[m].mean() - 1.0) < tol, (lo, hi)
 
 
 @pytest.mark.skipif(not os.path.exists(REF_SCENE), reason="reference tree not present")

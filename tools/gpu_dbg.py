@@ -1,27 +1,20 @@
-"""Scratch: image split debugging."""
+"""Scratch: GPU render of veach-mis against the reference's result.png (linear block means), by brightness band."""
 import sys
 sys.path[:0] = ['path-tracer_amd/python', 'oracle', 'tests']
 import numpy as np
-from pt_hip import api, synth
-sd = synth.cornell_box(200, 136)
-g = api.Scene(sd)
-for spp_pass in (0, 4):
-    whole, wst = g.render(0, 6, traversal=1, samples_per_pass=spp_pass)
-    print('whole', spp_pass, wst['paths'], wst['closest_rays'], wst['any_rays'])
-for mode in (0, 1):
-    for world in (2,):
-        total = np.zeros_like(whole)
-        for rank in range(world):
-            film, st = g.render(0, 6, traversal=mode, block=(rank, world), samples_per_pass=4)
-            print(' mode', mode, 'rank', rank, st['paths'], st['closest_rays'], st['any_rays'])
-            total += film
-        d = np.abs(total - whole)
-        print(' max diff', d.max(), 'n diff', (d > 1e-4).sum(), 'weight diff', np.abs(total[..., 3] - whole[..., 3]).max())
-        ys, xs = np.nonzero(d.max(-1) > 1e-4)
-        print(' where', list(zip(xs[:10], ys[:10])))
-a0, st = g.render(0, 6, traversal=1, integrator=api.INTEGRATOR_ALBEDO)
-t = np.zeros_like(a0)
-for rank in range(3):
-    f, st = g.render(0, 6, traversal=1, integrator=api.INTEGRATOR_ALBEDO, block=(rank, 3))
-    t += f
-print('albedo diff', np.abs(t - a0).max())
+import helpers
+from pt_hip import api
+from pt_hip.scene import SceneData
+want = np.load("tests/golden/veach_mis_result.npz")["linear"].astype(np.float64)
+g = api.Scene(SceneData.load('tests/golden/veach_mis_scene.npz'))
+bands = [0, 0.002, 0.005, 0.01, 0.02, 0.05, 0.1, 0.2, 0.5, 1.01]
+conv = helpers.png_block_means(api.film_to_image(g.render(5000, 7048, traversal=1)[0]))   # selector: converged, other samples
+lum = conv.mean(-1)
+for spp in (16, 256, 2048):
+    film, _ = g.render(0, spp, traversal=1)
+    got = helpers.png_block_means(api.film_to_image(film))
+    print('spp', spp, 'sum ratio', got.sum() / want.sum(), 'mean |d| / mean', np.abs(got - want).mean() / want.mean())
+    for lo, hi in zip(bands, bands[1:]):
+        m = (lum >= lo) & (lum < hi)
+        if m.any():
+            print('   band %.3f-%.3f frac %.3f ratio got/ref %.4f   ref/conv %.4f' % (lo, hi, m.mean(), got[m].mean() / want[m].mean(), want[m].mean() / conv[m].mean()))
