@@ -414,12 +414,16 @@ PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& redo
 
 // Any hit on the 2-wide layout.  The reference's distance bound is constant for this query, so the set of leaves it
 // reaches does not depend on the visit order: with identical box decisions and unconditional leaf visits this returns
-// exactly what the reference returns, whatever the order.
+// exactly what the reference returns, whatever the order.  One subtree more is left out: a box that the ray enters
+// (all three slabs) beyond its far end, widened by the kNearTie window, cannot hold a triangle that is accepted within
+// the ray's range -- the same margin between box entry and triangle distance that closest_ordered_t relies on -- so
+// visiting it, as the reference does because its test ignores the z slab's entry, never changes the answer.
 template <bool SPECIAL, class C>
 PTD bool any_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, uint32_t* lds_stack, C& wc) {
     uint32_t spill[kSpillDepth];
     Stack st;
     st.init(lds_stack, spill);
+    const float far_end = SPECIAL ? __builtin_huge_valf() : ray.tmax * (1.0f + kNearTie);  // NaN slabs: no extra skip
     uint32_t cur = sc.wide_root;
     for (;;) {
         if (cur & kLeafBit) {
@@ -440,11 +444,11 @@ PTD bool any_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, u
             bool go0 = true, go1 = true;
             if (!(r0 & kLeafBit)) {
                 const BoxT b = box_decide<SPECIAL>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
-                go0 = b.overlap && b.tn < ray.tmax;
+                go0 = b.overlap && b.tn < ray.tmax && (SPECIAL || b.order <= far_end);
             }
             if (!(r1 & kLeafBit)) {
                 const BoxT b = box_decide<SPECIAL>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
-                go1 = b.overlap && b.tn < ray.tmax;
+                go1 = b.overlap && b.tn < ray.tmax && (SPECIAL || b.order <= far_end);
             }
             if (go0 && go1) {
                 // a leaf first (cheap, may end the query); otherwise the first-listed child, which the builder made the

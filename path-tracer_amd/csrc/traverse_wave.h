@@ -105,12 +105,14 @@ struct ClosestLane {
 struct AnyLane {
     RayPre pre;
     float tmax;
+    float far_end;  // tmax widened by the near-tie window: a box the ray enters (all three slabs) beyond it is skipped
     bool occluded;
     uint32_t cur;
 
     PTD void begin(const DevScene& sc, const RayD& ray, const RayPre& p) {
         pre = p;
         tmax = ray.tmax;
+        far_end = ray.tmax * (1.0f + kNearTie);
         occluded = false;
         cur = sc.wide_root;
     }
@@ -125,7 +127,7 @@ struct AnyLane {
         const BoxT b0 = box_decide<false>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
         const BoxT b1 = box_decide<false>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
         const bool l0 = (r0 & kLeafBit) != 0u, l1 = (r1 & kLeafBit) != 0u;
-        const bool go0 = l0 || (b0.overlap && b0.tn < tmax), go1 = l1 || (b1.overlap && b1.tn < tmax);
+        const bool go0 = l0 || (b0.overlap && b0.tn < tmax && b0.order <= far_end), go1 = l1 || (b1.overlap && b1.tn < tmax && b1.order <= far_end);
         if (go0 && go1) {
             const bool swap = l1 && !l0;
             cur = swap ? r1 : r0;
