@@ -125,6 +125,7 @@ struct BoxT {
     bool overlap;  // slabs overlap and the x/y interval ends after ray.tmin
     float tn;      // x/y entry distance
     float order;
+    float leave;   // distance at which the ray leaves the box (all three slabs)
 };
 
 template <bool SPECIAL>
@@ -156,6 +157,7 @@ PTD BoxT box_decide(float lox, float loy, float loz, float hix, float hiy, float
         b.overlap = b.overlap && !((tmin > tzmax) || (tzmin > tmax)) && (tmax > r.tmin);
         b.tn = tmin;
         b.order = (tzmin > tmin) ? tzmin : tmin;
+        b.leave = (tzmax < tmax) ? tzmax : tmax;
         return b;
     }
     const float nx0 = lox - r.o.x, nx1 = hix - r.o.x, ny0 = loy - r.o.y, ny1 = hiy - r.o.y, nz0 = loz - r.o.z, nz1 = hiz - r.o.z;
@@ -170,6 +172,7 @@ PTD BoxT box_decide(float lox, float loy, float loz, float hix, float hiy, float
     b.overlap = (tn <= tf) && (tn <= zf) && (zn <= tf) && (tf > r.tmin);
     b.tn = tn;
     b.order = fmaxf(tn, zn);
+    b.leave = fminf(tf, zf);
     return b;
 }
 
@@ -308,12 +311,20 @@ PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uin
 // deciding whether visit order can matter (see closest_ordered_t).
 constexpr float kNearTie = 1.0f / 8192.0f;
 
+// A box that the ray has left (all three slabs) before its own near end holds no triangle that is accepted within the
+// ray's range; the reference still enters it when only the z slab lies behind the origin (its test looks at the x/y
+// exit alone).  Margin: kNearTie of the box's entry distance -- for a box that ends behind the ray's origin the entry is
+// the larger of its two distances, the scale of the rounding errors of the triangle distances inside the box.
+// Comparisons are false for NaN: callers use this for finite quotients only.
+PTD bool box_reaches_range(const BoxT& b, float tmin) { return __fmaf_rn(kNearTie, fabsf(b.order), b.leave) >= tmin; }
+
 // Ordered closest hit on the 2-wide layout.
 //
 // Same candidate set as the reference: an interior child is entered only if the reference's slab test accepts its box
 // (box_decide, identical decisions), leaf children are never box-tested (src/bvh.cpp:38-48), triangles use the same
-// test.  Differences: the nearer child is visited first, and a subtree is skipped when the distance at which the ray
-// enters its box (all three slabs) lies beyond the current best hit by more than the kNearTie window.
+// test.  Differences: the nearer child is visited first, a subtree is skipped when the distance at which the ray
+// enters its box (all three slabs) lies beyond the current best hit by more than the kNearTie window, and when the ray
+// has left its box before the near end of its range (box_reaches_range) -- neither subtree holds a candidate.
 //
 // When is the result the reference's?  Let G be the nearest accepted triangle among all leaves reachable through
 // accepted boxes.  If no other candidate (and not the ray's own far end) lies within the kNearTie window of t_G, then
@@ -365,12 +376,12 @@ PTD bool closest_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pr
             float o0 = -__builtin_huge_valf(), o1 = -__builtin_huge_valf();
             if (!(r0 & kLeafBit)) {
                 const BoxT b = box_decide<SPECIAL>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
-                go0 = b.overlap && b.order <= window;
+                go0 = b.overlap && b.order <= window && (SPECIAL || box_reaches_range(b, ray.tmin));
                 o0 = b.order;
             }
             if (!(r1 & kLeafBit)) {
                 const BoxT b = box_decide<SPECIAL>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
-                go1 = b.overlap && b.order <= window;
+                go1 = b.overlap && b.order <= window && (SPECIAL || box_reaches_range(b, ray.tmin));
                 o1 = b.order;
             }
             if (go0 && go1) {
@@ -414,10 +425,11 @@ PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& redo
 
 // Any hit on the 2-wide layout.  The reference's distance bound is constant for this query, so the set of leaves it
 // reaches does not depend on the visit order: with identical box decisions and unconditional leaf visits this returns
-// exactly what the reference returns, whatever the order.  One subtree more is left out: a box that the ray enters
-// (all three slabs) beyond its far end, widened by the kNearTie window, cannot hold a triangle that is accepted within
-// the ray's range -- the same margin between box entry and triangle distance that closest_ordered_t relies on -- so
-// visiting it, as the reference does because its test ignores the z slab's entry, never changes the answer.
+// exactly what the reference returns, whatever the order.  Two kinds of subtree are left out: a box that the ray enters
+// (all three slabs) beyond its far end, widened by the kNearTie window, and a box that it has left before its near end
+// (box_reaches_range).  Neither can hold a triangle that is accepted within the ray's range -- the same margin between
+// box and triangle distances that closest_ordered_t relies on -- so visiting them, as the reference does because its
+// test ignores the z slab's entry and exit, never changes the answer.
 template <bool SPECIAL, class C>
 PTD bool any_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, uint32_t* lds_stack, C& wc) {
     uint32_t spill[kSpillDepth];
@@ -444,11 +456,11 @@ PTD bool any_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, u
             bool go0 = true, go1 = true;
             if (!(r0 & kLeafBit)) {
                 const BoxT b = box_decide<SPECIAL>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
-                go0 = b.overlap && b.tn < ray.tmax && (SPECIAL || b.order <= far_end);
+                go0 = b.overlap && b.tn < ray.tmax && (SPECIAL || (b.order <= far_end && box_reaches_range(b, ray.tmin)));
             }
             if (!(r1 & kLeafBit)) {
                 const BoxT b = box_decide<SPECIAL>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
-                go1 = b.overlap && b.tn < ray.tmax && (SPECIAL || b.order <= far_end);
+                go1 = b.overlap && b.tn < ray.tmax && (SPECIAL || (b.order <= far_end && box_reaches_range(b, ray.tmin)));
             }
             if (go0 && go1) {
                 // a leaf first (cheap, may end the query); otherwise the first-listed child, which the builder made the
