@@ -318,6 +318,14 @@ constexpr float kNearTie = 1.0f / 8192.0f;
 // Comparisons are false for NaN: callers use this for finite quotients only.
 PTD bool box_reaches_range(const BoxT& b, float tmin) { return __fmaf_rn(kNearTie, fabsf(b.order), b.leave) >= tmin; }
 
+// Leaf children are not box-tested by the reference (src/bvh.cpp:38-48): their triangles are simply tried.  A leaf whose
+// box the ray misses by more than the same margin (it enters, all three slabs, after it has left; or outside the
+// range [tmin, bound]) cannot have an accepted triangle, so the ordered traversal does not fetch it.
+PTD bool leaf_worth_a_visit(const BoxT& b, float tmin, float bound) {
+    const float leave = __fmaf_rn(kNearTie, fabsf(b.order), b.leave);
+    return b.order <= leave && leave >= tmin && b.order <= bound;
+}
+
 // Ordered closest hit on the 2-wide layout.
 //
 // Same candidate set as the reference: an interior child is entered only if the reference's slab test accepts its box

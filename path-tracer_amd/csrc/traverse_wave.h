@@ -61,7 +61,8 @@ struct ClosestLane {
         const BoxT b0 = box_decide<false>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
         const BoxT b1 = box_decide<false>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
         const bool l0 = (r0 & kLeafBit) != 0u, l1 = (r1 & kLeafBit) != 0u;
-        const bool go0 = l0 || (b0.overlap && b0.order <= window && box_reaches_range(b0, pre.tmin)), go1 = l1 || (b1.overlap && b1.order <= window && box_reaches_range(b1, pre.tmin));
+        const bool go0 = l0 ? leaf_worth_a_visit(b0, pre.tmin, window) : (b0.overlap && b0.order <= window && box_reaches_range(b0, pre.tmin));
+        const bool go1 = l1 ? leaf_worth_a_visit(b1, pre.tmin, window) : (b1.overlap && b1.order <= window && box_reaches_range(b1, pre.tmin));
         const float o0 = l0 ? -__builtin_huge_valf() : b0.order, o1 = l1 ? -__builtin_huge_valf() : b1.order;
         if (go0 && go1) {
             const bool swap = o1 < o0;
@@ -127,7 +128,8 @@ struct AnyLane {
         const BoxT b0 = box_decide<false>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
         const BoxT b1 = box_decide<false>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
         const bool l0 = (r0 & kLeafBit) != 0u, l1 = (r1 & kLeafBit) != 0u;
-        const bool go0 = l0 || (b0.overlap && b0.tn < tmax && b0.order <= far_end && box_reaches_range(b0, pre.tmin)), go1 = l1 || (b1.overlap && b1.tn < tmax && b1.order <= far_end && box_reaches_range(b1, pre.tmin));
+        const bool go0 = l0 ? leaf_worth_a_visit(b0, pre.tmin, far_end) : (b0.overlap && b0.tn < tmax && b0.order <= far_end && box_reaches_range(b0, pre.tmin));
+        const bool go1 = l1 ? leaf_worth_a_visit(b1, pre.tmin, far_end) : (b1.overlap && b1.tn < tmax && b1.order <= far_end && box_reaches_range(b1, pre.tmin));
         if (go0 && go1) {
             const bool swap = l1 && !l0;
             cur = swap ? r1 : r0;
