@@ -88,6 +88,10 @@ PTD bool last_block_of_shard(uint32_t* done, uint32_t shard) {
 #ifndef WPE
 #define WPE 6
 #endif
+// LDS rows per lane of the kernels built on closest_wave: references and entry distances of its stack; the same memory
+// then serves the follow-up traversals of deferred rays as a plain stack of kLdsDepth rows.
+constexpr int kWaveRows = 2 * kDistRows;
+static_assert(kWaveRows >= kLdsDepth, "the follow-up traversals use the same LDS as a plain stack");
 constexpr uint32_t kMaxWaveBlocks = 8;  // workgroups per shard of the wave-refill kernels: between 2 and 8, see wave_blocks()
 constexpr uint32_t kMinWaveBlocks = 2;
 constexpr uint32_t kShadeBlocks = 8;  // most workgroups per shard of k_shade (256 threads each), see shade_blocks()
@@ -352,7 +356,7 @@ template <class C>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_generate_wave(DevScene sc, GenerateIo io,
                                                                                                                   uint32_t* fetch, uint32_t* done,
                                                                                                                   uint32_t* misc) {
-    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    __shared__ uint32_t s_stack[kWaveRows * kBlock];
     const uint32_t shard = blockIdx.y;
     C wc;
     closest_wave(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
@@ -496,7 +500,7 @@ PTD void extend_deferred(const DevScene& sc, const PathQ& q, const HitQ& hq, con
 template <class C>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_extend_wave(DevScene sc, ExtendIo io, uint32_t* fetch,
                                                                                                     uint32_t* done, ZeroList zl, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    __shared__ uint32_t s_stack[kWaveRows * kBlock];
     const uint32_t shard = blockIdx.y;
     zero_counters(zl, shard);
     C wc;
@@ -591,7 +595,7 @@ struct BatchClosestIo {
 
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_intersect_wave(DevScene sc, BatchClosestIo io, uint32_t* fetch, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    __shared__ uint32_t s_stack[kWaveRows * kBlock];
     C wc;
     closest_wave(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
     flush_counts(wc, misc, 1);

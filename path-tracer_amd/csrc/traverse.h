@@ -59,6 +59,45 @@ struct Stack {
     PTD bool empty() const { return sp == 0; }
 };
 
+// Stack of the wave-level ordered closest-hit traversal: a deferred subtree is kept together with the distance at which
+// the ray enters its box, so that a subtree that lies beyond the best hit by the time it is popped is dropped without
+// its node being fetched.  kDistRows entries per lane in LDS (references in rows [0, kDistRows), distances in rows
+// [kDistRows, 2 kDistRows) of a [row][lane] array), the rest in two private arrays.
+constexpr int kDistRows = 12;
+constexpr int kDistSpill = kMaxStack - kDistRows;
+
+struct DistStack {
+    lds_u32* lds;
+    private_u32* spill;    // kDistSpill references, then kDistSpill distances
+    int sp;
+    PTD void init(uint32_t* base, uint32_t* spill_words) {
+        lds = (lds_u32*)base;
+        spill = (private_u32*)spill_words;
+        sp = 0;
+    }
+    PTD void push(uint32_t v, float d) {
+        if (sp < kDistRows) {
+            lds[sp * kBlock] = v;
+            lds[(sp + kDistRows) * kBlock] = __float_as_uint(d);
+        } else {
+            spill[sp - kDistRows] = v;
+            spill[sp - kDistRows + kDistSpill] = __float_as_uint(d);
+        }
+        ++sp;
+    }
+    PTD void pop(uint32_t& v, float& d) {
+        --sp;
+        if (sp < kDistRows) {
+            v = lds[sp * kBlock];
+            d = __uint_as_float(lds[(sp + kDistRows) * kBlock]);
+        } else {
+            v = spill[sp - kDistRows];
+            d = __uint_as_float(spill[sp - kDistRows + kDistSpill]);
+        }
+    }
+    PTD bool empty() const { return sp == 0; }
+};
+
 struct RayD {
     V3 o, d;
     float tmin, tmax;

@@ -49,11 +49,23 @@ struct ClosestLane {
         hit = HitD{-1, 0.0f, 0.0f, 0.0f};
         cur = sc.wide_root;
     }
-    PTD void next(Stack& st) { cur = st.empty() ? kDone : st.pop(); }
+    // the nearest deferred subtree that can still hold a candidate
+    PTD void next(DistStack& st) {
+        cur = kDone;
+        while (!st.empty()) {
+            uint32_t ref;
+            float entry;
+            st.pop(ref, entry);
+            if (entry <= window) {
+                cur = ref;
+                break;
+            }
+        }
+    }
 
-    // one 2-wide node: both boxes are evaluated without branching, leaf children are taken unconditionally
+    // one 2-wide node: both boxes are evaluated without branching
     template <class C>
-    PTD void inner(const DevScene& sc, Stack& st, C& wc) {
+    PTD void inner(const DevScene& sc, DistStack& st, C& wc) {
         const float4* w = sc.wide + 4 * size_t(cur);
         wc.node();
         const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
@@ -67,7 +79,7 @@ struct ClosestLane {
         if (go0 && go1) {
             const bool swap = o1 < o0;
             cur = swap ? r1 : r0;
-            st.push(swap ? r0 : r1);
+            st.push(swap ? r0 : r1, swap ? b0.order : b1.order);
         } else if (go0 || go1) {
             cur = go0 ? r0 : r1;
         } else {
@@ -76,7 +88,7 @@ struct ClosestLane {
     }
 
     template <class C>
-    PTD void leaf(const DevScene& sc, Stack& st, C& wc) {
+    PTD void leaf(const DevScene& sc, DistStack& st, C& wc) {
         const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
         for (uint32_t k = 0; k < count; ++k) {
             V3 p0, e1, e2;
@@ -183,11 +195,12 @@ PTD uint32_t wave_fetch(bool want, uint32_t* counter, uint32_t count, bool& more
 //   bool load(sc, shard, j, RayD&, Carry&)                     ray j and whatever the caller wants back at commit time;
 //                                                           false = position j holds no query (reported as a miss)
 //   void commit(sc, shard, fin, j, hit, defer, bound, carry, o, d)   called by the whole wave; fin marks lanes with a result
+// lds_stack: this lane's column of a [2 * kDistRows][kBlock] array of words.
 template <class Io, class C>
 PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, C& wc) {
     const uint32_t count = io.count(shard);
-    uint32_t spill[kSpillDepth];
-    Stack st;
+    uint32_t spill[2 * kDistSpill];
+    DistStack st;
     st.init(lds_stack, spill);
     ClosestLane L;
     L.cur = kDone;
