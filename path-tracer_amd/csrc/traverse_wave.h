@@ -14,9 +14,15 @@
 namespace ptd {
 
 constexpr uint32_t kDone = kLeafBit;     // a leaf reference without triangles: nothing left to visit
-// Measured on a 1.6 M triangle interior scene: flat optimum around these values (refill 16..48, box lanes 24..40).
-constexpr uint32_t kRefillBelow = 32;    // fetch new rays once fewer lanes than this are busy
-constexpr uint32_t kMinBoxLanes = 28;    // leave the box phase for the triangle phase once fewer lanes than this have a box step to do
+// Measured on a 1.6 M triangle interior scene: flat optimum around these values (refill 20..48, box lanes 12..40: within 3 %).
+#ifndef PT_REFILL_BELOW
+#define PT_REFILL_BELOW 24
+#endif
+#ifndef PT_MIN_BOX_LANES
+#define PT_MIN_BOX_LANES 20
+#endif
+constexpr uint32_t kRefillBelow = PT_REFILL_BELOW;   // fetch new rays once fewer lanes than this are busy
+constexpr uint32_t kMinBoxLanes = PT_MIN_BOX_LANES;  // leave the box phase for the triangle phase once fewer lanes than this have a box step to do
 
 PTD uint32_t lane_id() { return __lane_id(); }
 
