@@ -523,3 +523,34 @@ def test_full_size_library_workload_properties():
     assert helpers.rel_mse(api.film_to_image(a), orc.film_to_image(want)) < 1e-4
     assert abs(sa["closest_rays"] - ost["closest_rays"]) <= 1e-4 * ost["closest_rays"]
     g.close()
+
+
+def test_full_size_bathroom_workload_properties():
+    """The textured stand-in at its full size (0.44 M triangles, 768x768, a mirror, per-vertex normals): both traversal
+    orders agree bit for bit on a million random rays inside the room, a sample of them equals the oracle's hits, and a
+    render takes the same paths in both modes."""
+    sd = synth.bathroom_synth()
+    o, g = orc.Scene(sd), api.Scene(sd)
+    lo, hi = sd.verts.min(0), sd.verts.max(0)
+    rng = np.random.default_rng(17)
+    n = 1 << 20
+    org = rng.uniform(lo + 0.02 * (hi - lo), hi - 0.02 * (hi - lo), (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::997, 0] = 0.0                                     # some axis-parallel rays (plain-division path)
+    rays = np.concatenate([org, d, np.zeros((n, 1), np.float32), np.full((n, 1), np.inf, np.float32)], 1).astype(np.float32)
+    he, hf = g.intersect(rays, api.TRAVERSE_EXACT), g.intersect(rays, api.TRAVERSE_FAST)
+    assert np.array_equal(he.view(np.uint32), hf.view(np.uint32))
+    assert (he["prim"] >= 0).mean() > 0.9
+    sub = slice(0, n, 61)
+    assert helpers.hits_equal(he[sub], o.intersect(rays[sub])).all()
+    rays[:, 7] = rng.uniform(0.02, 1.0, n).astype(np.float32) * float(np.linalg.norm(hi - lo))
+    oe, _ = g.occluded(rays, api.TRAVERSE_EXACT)
+    assert np.array_equal(oe, g.occluded(rays, api.TRAVERSE_FAST)[0])
+    assert np.array_equal(oe[sub], o.occluded(rays[sub])[0])
+    assert 0.05 < oe.mean() < 0.95
+    f, sf = g.render(0, 4, traversal=api.TRAVERSE_FAST)
+    e, se = g.render(0, 4, traversal=api.TRAVERSE_EXACT)
+    assert (se["closest_rays"], se["any_rays"]) == (sf["closest_rays"], sf["any_rays"])
+    assert np.allclose(e, f, rtol=1e-4, atol=1e-5)
+    g.close()
