@@ -115,11 +115,12 @@ typedef struct pt_hit {
  * EXACT replays the reference's visit order on the binary tree (src/bvh.cpp:26-86): pop, cull interior nodes with the
  * current max distance, never box-test leaves, accept t <= max, last accepted wins.
  * FAST is an ordered (near child first, distance-culled) traversal of a 2-wide node layout built from the same tree.
- * It takes the reference's own accept/reject decision for every box, visits leaves unconditionally as the reference
- * does, and repeats a query in the reference's order whenever two candidates (or a candidate and the ray's far end) lie
- * within a 2^-13 relative distance of each other, so that the reported triangle, t, u and v are the reference's in
- * both modes; occlusion queries are order-independent by construction.  For occluded rays FAST reports first_prim = -2
- * (the "first accepted triangle" is a property of the reference's visit order). */
+ * An interior box is entered only if the reference's own test accepts it and the ray's three-slab interval through it
+ * can hold an acceptable triangle (the reference's test ignores the z slab's entry and exit when it compares with the
+ * ray's range); a query is repeated in the reference's order whenever two candidates (or a candidate and the ray's far
+ * end) lie within a 2^-13 relative distance of each other, so that the reported triangle, t, u and v are the
+ * reference's in both modes; occlusion queries are order-independent by construction.  For occluded rays FAST reports
+ * first_prim = -2 (the "first accepted triangle" is a property of the reference's visit order). */
 enum { PT_TRAVERSE_EXACT = 0, PT_TRAVERSE_FAST = 1 };
 
 /* Integrators (src/integrator.cpp): MIS path tracer :45-141, shading normal :20-31, base colour :33-43. */
