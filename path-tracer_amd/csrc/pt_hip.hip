@@ -49,6 +49,22 @@ inline uint32_t sobol_word(uint64_t index, int dim) {  // the XOR part of sobolS
         if (index & 1) v ^= kSobolMatrices32[i];
     return v;
 }
+// The same for all 1024 dimensions of one index: row `bit` of the transposed table holds that bit's generator word of
+// every dimension, so the whole row of a sample number is a handful of 1024-word XORs.
+inline void sobol_words_all_dims(uint64_t index, uint32_t* out) {
+    static const std::vector<uint32_t> by_bit = [] {
+        std::vector<uint32_t> t(size_t(52) * 1024);
+        for (int dim = 0; dim < 1024; ++dim)
+            for (int bit = 0; bit < 52; ++bit) t[size_t(bit) * 1024 + dim] = kSobolMatrices32[dim * 52 + bit];
+        return t;
+    }();
+    std::memset(out, 0, 1024 * sizeof(uint32_t));
+    for (int bit = 0; index != 0; index >>= 1, ++bit) {
+        if (!(index & 1)) continue;
+        const uint32_t* row = by_bit.data() + size_t(bit) * 1024;
+        for (int dim = 0; dim < 1024; ++dim) out[dim] ^= row[dim];
+    }
+}
 inline int32_t round_up_pow2(int32_t v) {  // src/sampler.cpp:68-76
     v--;
     v |= v >> 1;
@@ -963,7 +979,7 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         frame_words.resize(size_t(nf) * 1024);
         for (uint32_t k = 0; k < nf; ++k) {
             const uint64_t idx = frame_index(s->sob_m, uint64_t(f0) + k);
-            for (int dim = 0; dim < 1024; ++dim) frame_words[size_t(k) * 1024 + dim] = sobol_word(idx, dim);
+            sobol_words_all_dims(idx, frame_words.data() + size_t(k) * 1024);
         }
         HIP_TRY(hipMemcpyAsync(ws.frame_tab, frame_words.data(), frame_words.size() * 4, hipMemcpyHostToDevice, g_stream));
         PassArgs pa{};
@@ -1038,7 +1054,7 @@ int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pi
     std::vector<uint32_t> frame_words(local.size() * 1024);
     for (const auto& kv : local) {
         const uint64_t idx = frame_index(s->sob_m, kv.first);
-        for (int dim = 0; dim < 1024; ++dim) frame_words[size_t(kv.second) * 1024 + dim] = sobol_word(idx, dim);
+        sobol_words_all_dims(idx, frame_words.data() + size_t(kv.second) * 1024);
     }
     if (int rc = ws_reserve(s->ws, uint32_t(n), local.size())) return rc;
     Workspace& ws = s->ws;
@@ -1133,7 +1149,7 @@ int pt_hip_sobol(pt_hip_scene* s, const int32_t* pixel_xy, const uint32_t* sampl
     std::vector<uint32_t> frame_words(local.size() * 1024);
     for (const auto& kv : local) {
         const uint64_t idx = frame_index(s->sob_m, kv.first);
-        for (int d = 0; d < 1024; ++d) frame_words[size_t(kv.second) * 1024 + d] = sobol_word(idx, d);
+        sobol_words_all_dims(idx, frame_words.data() + size_t(kv.second) * 1024);
     }
     void *d_tab = nullptr, *d_xy = nullptr, *d_fl = nullptr, *d_dim = nullptr, *d_out = nullptr;
     auto cleanup = [&]() {
