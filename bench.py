@@ -154,11 +154,12 @@ def main():
         achieved = units[dominant] * per_unit[dominant] / (kms[dominant] * 1e-3) / 1e9 if kms[dominant] > 0 else 0.0
         # HBM-side bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be
         # read from inside this process); the committed figure is quoted when it is for this workload and kernel
-        traffic, traffic_note = None, None
+        traffic, traffic_note, counters = None, None, None
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s/%s" % (a.workload, a.traversal))
             if t and t["kernel"] == "k_" + dominant and t["bytes_per_launch"]:
                 traffic, traffic_note = t["bytes_per_launch"], "%s; %s" % (t["source"], t["how"])
+                counters = {k: t[k] for k in ("valu_issue_frac", "lanes_per_valu_inst_frac", "l2_hit_rate") if k in t}
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -176,6 +177,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_note,
+                         # from the same committed counter pass: what the kernel is really bound by (VALU issue slots in use,
+                         # share of the 64 lanes active per VALU instruction, L2 hit rate)
+                         "counters": counters,
                          "note": "achieved counts ALGORITHMIC bytes (records fetched by the traversal + queue entries); most of them are served by "
                                  "L2 / Infinity Cache, not HBM, so the fraction can approach or exceed 1: compare with traffic", "algorithmic_bytes_per_launch": per_unit[dominant] * units[dominant] / max(kn[dominant], 1),
                          "bytes_per_unit": per_unit[dominant], "units_per_launch": units[dominant] / max(kn[dominant], 1),

@@ -39,6 +39,10 @@ for key, kern, name in (("library-synth/fast", "k_extend_wave", "library128spp")
     t[key]["source"] = rel
     t[key]["how"] = re.sub(r"over the \d+ ", "over the %d " % n, t[key]["how"])
     p1, p2 = row(path, "pmc1", kern), row(path, "pmc2", kern)
+    # SQ_INSTS_VALU x 4 cycles over the SIMD cycles of the launches (1024 SIMDs at 2.4 GHz); active lanes per VALU instruction
+    t[key]["valu_issue_frac"] = round(p1[4] * 4 / (p1[0] * 1e-6 * 2.4e9 * 1024), 3)
+    t[key]["lanes_per_valu_inst_frac"] = round(p2[6] / (p2[2] * 64), 3)
+    t[key]["l2_hit_rate"] = round(v[4] / (v[4] + v[5]), 3)
     print(key, "launches", n, "fabric bytes/launch %.3g" % t[key]["bytes_per_launch"], "L2 hit %.3f" % (v[4] / (v[4] + v[5])),
           "VALU issue %.3f" % (p1[4] * 4 / (p1[0] * 1e-6 * 2.4e9 * 1024)), "lanes per VALU instruction %.3f" % (p2[6] / (p2[2] * 64)))
 json.dump(t, open(os.path.join(P, "traffic.json"), "w"), indent=1)
