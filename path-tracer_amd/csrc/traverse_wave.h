@@ -3,10 +3,12 @@
 //   - box steps and triangle steps run in separate phases (all lanes of a phase execute the same code), and
 //   - lanes whose query has ended take the next ray from the queue as soon as too few lanes are left busy, instead of
 //     idling until the slowest lane of the wave is done.
-// The per-node work is exactly that of closest_ordered_t / any_ordered_t (traverse.h): same box decisions, same
-// candidate set, same near-tie detection.  Rays that need the plain-division slab test ("special") and queries whose
-// result could depend on the visit order are not handled here; they are handed back to the caller (`defer`), which
-// runs them through closest_fast / closest_exact_t / any_fast in a follow-up kernel.
+// The per-node work is that of closest_ordered_t / any_ordered_t (traverse.h): same box decisions, same near-tie
+// detection, and the same accepted triangles -- the wave form leaves out a little more that cannot hold one: leaves
+// whose box the ray misses (leaf_worth_a_visit) and, for closest hits, deferred subtrees that have fallen behind the best
+// hit by the time they are popped (DistStack).  Rays that need the plain-division slab test ("special") and queries
+// whose result could depend on the visit order are not handled here; they are handed back to the caller (`defer`),
+// which runs them through closest_fast / closest_exact_t / any_fast in a follow-up kernel.
 #pragma once
 
 #include "traverse.h"
