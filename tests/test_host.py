@@ -192,6 +192,32 @@ def test_library_exports_every_declared_symbol(header, libname):
         assert hasattr(lib, n), n
 
 
+def test_headers_are_plain_c_and_the_binding_mirrors_their_layout(tmp_path):
+    """include/*.h compile as C99 on their own, and every struct has the size and field offsets the ctypes binding
+    assumes (the binding is hand-written: this is what catches it drifting from the header)."""
+    import subprocess
+    inc = os.path.join(os.path.dirname(api.LIB_DIR), "..", "include")
+    mirror = {"pt_bvh_node": api.BvhNode, "pt_material": api.Material, "pt_light": api.Light, "pt_texture": api.Texture,
+              "pt_camera": api.Camera, "pt_scene_desc": api.SceneDesc, "pt_render_params": api.RenderParams, "pt_stats": api.Stats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pt_hip.h"', '#include "pt_host.h"', 'int main(void) {']
+    for cname, cls in mirror.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        lines.append('printf("\\n");')
+    lines += ['printf("pt_ray %zu\\n", sizeof(pt_ray)); printf("pt_hit %zu\\n", sizeof(pt_hit));', 'return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, str(src), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = dict((l.split()[0], [int(v) for v in l.split()[1:]]) for l in subprocess.run([exe], capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in mirror.items():
+        assert out[cname][0] == C.sizeof(cls), cname
+        assert out[cname][1:] == [getattr(cls, f).offset for f, _ in cls._fields_], cname
+    assert out["pt_ray"] == [api.RAY_DTYPE.itemsize] and out["pt_hit"] == [api.HIT_DTYPE.itemsize]
+
+
 def test_hip_library_reports_errors_without_a_gpu_or_init():
     lib = api.hip_lib()
     assert lib.pt_hip_abi_version() == 1
