@@ -95,7 +95,6 @@ static_assert(kWaveRows >= kLdsDepth, "the follow-up traversals use the same LDS
 constexpr uint32_t kMaxWaveBlocks = 8;  // workgroups per shard of the wave-refill kernels: between 2 and 8, see wave_blocks()
 constexpr uint32_t kMinWaveBlocks = 2;
 constexpr uint32_t kShadeBlocks = 8;  // most workgroups per shard of k_shade (256 threads each), see shade_blocks()
-constexpr uint32_t kExactBlocks = 16; // workgroups per shard of the reference-order traversal kernels  // workgroups per shard of a wave-refill kernel: 16 waves share a shard's queue
 
 struct PassArgs {
     const uint32_t* frame_tab;  // [frame_local][1024] Sobol' words of the sample numbers of this pass
@@ -126,15 +125,6 @@ PTD bool trace_closest(const DevScene& sc, int traversal, const RayD& ray, HitD&
     const bool found = closest_fast(sc, ray, hit, redo, lds, wc);
     if (redo && retrace_counter) atomicAdd(retrace_counter, 1u);
     return found;
-}
-
-template <class C>
-PTD bool trace_any(const DevScene& sc, int traversal, const RayD& ray, uint32_t* lds, C& wc) {
-    if (traversal == 0) {
-        int32_t fp;
-        return any_exact(sc, ray, fp, lds, wc);
-    }
-    return any_fast(sc, ray, lds, wc);
 }
 
 // add a wave's work counters to the global 64-bit totals (counting builds only)
@@ -352,14 +342,14 @@ struct GenerateIo {
     }
 };
 
-template <class C>
+template <class C, class Lane>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_generate_wave(DevScene sc, GenerateIo io,
                                                                                                                   uint32_t* fetch, uint32_t* done,
                                                                                                                   uint32_t* misc) {
     __shared__ uint32_t s_stack[kWaveRows * kBlock];
     const uint32_t shard = blockIdx.y;
     C wc;
-    closest_wave(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
+    closest_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
     if (last_block_of_shard(done, shard)) {
         const size_t sbase = size_t(shard) * kShard;
         const uint32_t n = load_fresh(io.dq.count + shard);
@@ -374,7 +364,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE
                 const float bound = as_f(load_fresh(&io.dq.e[sbase + k].y));
                 io.load(sc, shard, j, ray, c);
                 bool redo = true;
-                if (bound == __builtin_huge_valf()) {
+                if (bound == kDeferExact) {
+                    closest_exact(sc, ray, h, s_stack + threadIdx.x, wc);
+                    redo = false;
+                } else if (bound == __builtin_huge_valf()) {
                     closest_fast(sc, ray, h, redo, s_stack + threadIdx.x, wc);
                 } else {
                     const RayPre pre = make_pre(sc, ray);
@@ -388,42 +381,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE
     flush_counts(wc, misc, 0);
 }
 
-// ------------------------------------------------------------------------------------------------ extend (bounce >= 1)
-
-// Scene::rayIntersect for rays spawned by Intersection::genRay (src/shape.cpp:186-189): tmin 0, tmax +inf.
-// Hits are appended to the shard's hit list; a miss ends the path (src/integrator.cpp:53) and is simply not listed.
-template <class C>
-__global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, PathQ q, HitQ hq, int traversal, ZeroList zl, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
-    const uint32_t shard = blockIdx.y;
-    zero_counters(zl, shard);
-    const size_t sbase = size_t(shard) * kShard;
-    const uint32_t n = q.count[shard];
-    C wc;
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const uint32_t j = base + threadIdx.x;
-        bool found = false;
-        HitD h{-1, 0.0f, 0.0f, 0.0f};
-        float4 c{};
-        if (j < n) {
-            const float4 a = q.a[sbase + j], b = q.b[sbase + j];
-            c = q.c[sbase + j];
-            const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
-            found = trace_closest(sc, traversal, ray, h, s_stack + threadIdx.x, misc, wc);
-        }
-        const uint32_t local = wave_alloc(found, hq.count + shard);
-        if (found) {
-            hq.h0[sbase + local] = make_float4(as_f(j), as_f(uint32_t(h.prim)), h.u, h.v);
-            hq.h1[sbase + local] = make_float4(c.z, c.w, h.t, 0.0f);
-        }
-    }
-    flush_counts(wc, misc, 1);
-}
-
 // ------------------------------------------------------------------------------------------------ wave-refill variants
 
-// Ordered-mode extend: same inputs and outputs as k_extend, rays taken from the shard's queue through a fetch counter
-// (closest_wave).  Hits go to the hit list; deferred rays go to `dq` and are finished by the shard's last workgroup.
+// Scene::rayIntersect for rays spawned by Intersection::genRay (src/shape.cpp:186-189): tmin 0, tmax +inf.  Rays are taken
+// from the shard's queue through a fetch counter (closest_wave, in either traversal order).  Hits are appended to the
+// shard's hit list; a miss ends the path (src/integrator.cpp:53) and is simply not listed; deferred rays go to `dq` and are
+// finished by the shard's last workgroup.
 struct ExtendIo {
     PathQ q;
     HitQ hq;
@@ -479,7 +442,10 @@ PTD void extend_deferred(const DevScene& sc, const PathQ& q, const HitQ& hq, con
             c = q.c[sbase + j];
             const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
             bool redo = true;
-            if (bound == __builtin_huge_valf()) {
+            if (bound == kDeferExact) {
+                found = closest_exact(sc, ray, h, lds_stack, wc);
+                redo = false;
+            } else if (bound == __builtin_huge_valf()) {
                 found = closest_fast(sc, ray, h, redo, lds_stack, wc);
             } else {
                 const RayPre pre = make_pre(sc, ray);
@@ -497,19 +463,20 @@ PTD void extend_deferred(const DevScene& sc, const PathQ& q, const HitQ& hq, con
 
 // gridDim.x workgroups share a shard's queue; the last one to run dry also finishes the shard's deferred rays, so that
 // this (slow, nearly serial) work overlaps with the other shards instead of forming a tail of its own.
-template <class C>
+template <class C, class Lane>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_extend_wave(DevScene sc, ExtendIo io, uint32_t* fetch,
                                                                                                     uint32_t* done, ZeroList zl, uint32_t* misc) {
     __shared__ uint32_t s_stack[kWaveRows * kBlock];
     const uint32_t shard = blockIdx.y;
     zero_counters(zl, shard);
     C wc;
-    closest_wave(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
+    closest_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
     if (last_block_of_shard(done, shard)) extend_deferred(sc, io.q, io.hq, io.dq, shard, s_stack + threadIdx.x, misc, wc);
     flush_counts(wc, misc, 1);
 }
 
-// Ordered-mode shadow: same inputs and outputs as k_shadow (any_wave); plain-division rays go to `dq`.
+// Visibility test of sampleLd (src/integrator.cpp:124-126) through any_wave, in either traversal order: unoccluded rays
+// add their contribution to the sample's radiance slot; plain-division rays go to `dq`.
 struct ShadowIo {
     ShadowQ sh;
     DeferQ dq;
@@ -542,13 +509,13 @@ struct ShadowIo {
     }
 };
 
-template <class C>
+template <class C, class Lane>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_shadow_wave(DevScene sc, ShadowIo io, uint32_t* fetch,
                                                                                                     uint32_t* done, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t shard = blockIdx.y;
     C wc;
-    any_wave(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
+    any_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
     if (last_block_of_shard(done, shard)) {  // plain-division rays of the shard
         const size_t sbase = size_t(shard) * kShard;
         const uint32_t n = load_fresh(io.dq.count + shard);
@@ -556,7 +523,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE
             const uint32_t j = load_fresh(&io.dq.e[sbase + k].x);
             const float4 a = io.sh.a[sbase + j], b = io.sh.b[sbase + j];
             const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
-            if (!any_fast(sc, ray, s_stack + threadIdx.x, wc)) {
+            int32_t first_prim;
+            if (!(Lane::kReferenceOrder ? any_exact(sc, ray, first_prim, s_stack + threadIdx.x, wc) : any_fast(sc, ray, s_stack + threadIdx.x, wc))) {
                 const float4 v = io.sh.c[sbase + j];
                 const uint32_t slot = as_u(b.w);
                 float4 L = io.lbuf[slot];
@@ -597,7 +565,7 @@ template <class C>
 __global__ __launch_bounds__(kBlock) void k_intersect_wave(DevScene sc, BatchClosestIo io, uint32_t* fetch, uint32_t* misc) {
     __shared__ uint32_t s_stack[kWaveRows * kBlock];
     C wc;
-    closest_wave(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
+    closest_wave<ClosestLane>(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
     flush_counts(wc, misc, 1);
 }
 
@@ -646,7 +614,7 @@ template <class C>
 __global__ __launch_bounds__(kBlock) void k_occluded_wave(DevScene sc, BatchAnyIo io, uint32_t* fetch, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     C wc;
-    any_wave(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
+    any_wave<AnyLane>(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
     flush_counts(wc, misc, 2);
 }
 
@@ -813,32 +781,6 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq
             out.slot[sbase + nl] = slot;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------ shadow
-
-// Visibility test of sampleLd (src/integrator.cpp:124-126): unoccluded rays add their contribution.
-template <class C>
-__global__ __launch_bounds__(kBlock) void k_shadow(DevScene sc, ShadowQ sh, int traversal, float4* lbuf, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
-    const uint32_t shard = blockIdx.y;
-    const size_t sbase = size_t(shard) * kShard;
-    const uint32_t n = sh.count[shard];
-    C wc;
-    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += gridDim.x * kBlock) {
-        const float4 a = sh.a[sbase + j], b = sh.b[sbase + j];
-        const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
-        if (!trace_any(sc, traversal, ray, s_stack + threadIdx.x, wc)) {
-            const float4 c = sh.c[sbase + j];
-            const uint32_t slot = as_u(b.w);
-            float4 L = lbuf[slot];
-            L.x += c.x;
-            L.y += c.y;
-            L.z += c.z;
-            lbuf[slot] = L;
-        }
-    }
-    flush_counts(wc, misc, 2);
 }
 
 // ------------------------------------------------------------------------------------------------ film

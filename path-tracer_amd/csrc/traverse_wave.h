@@ -41,7 +41,24 @@ PTD uint32_t wave_alloc(bool want, uint32_t* counter) {
     return base + uint32_t(__popcll(mask & ((1ull << lane_id()) - 1ull)));
 }
 
+// Lane interface of the shared loops (closest_wave / any_wave):
+//   StackT, kSpillWords            the lane's stack type and the private words it needs
+//   idle()                         put the lane into the "nothing to do" state
+//   begin(sc, ray, pre)            start a query
+//   box_ready() / leaf_ready()     the next step is a box step / a triangle step
+//   finished()                     the query has ended
+//   inner(sc, st, wc), leaf(sc, st, wc)
 struct ClosestLane {
+    typedef DistStack StackT;
+    static constexpr int kSpillWords = 2 * kDistSpill;
+    static constexpr bool kReferenceOrder = false;
+    PTD void idle() {
+        cur = kDone;
+        hit = HitD{-1, 0.0f, 0.0f, 0.0f};
+    }
+    PTD bool box_ready() const { return !(cur >> 31); }
+    PTD bool leaf_ready() const { return cur > kDone; }
+    PTD bool finished() const { return cur == kDone; }
     RayPre pre;
     float tmax;
     float best, window;
@@ -124,6 +141,16 @@ struct ClosestLane {
 };
 
 struct AnyLane {
+    typedef Stack StackT;
+    static constexpr int kSpillWords = kSpillDepth;
+    static constexpr bool kReferenceOrder = false;
+    PTD void idle() {
+        cur = kDone;
+        occluded = false;
+    }
+    PTD bool box_ready() const { return !(cur >> 31); }
+    PTD bool leaf_ready() const { return cur > kDone; }
+    PTD bool finished() const { return cur == kDone; }
     RayPre pre;
     float tmax;
     float far_end;  // tmax widened by the near-tie window: a box the ray enters (all three slabs) beyond it is skipped
@@ -180,6 +207,150 @@ struct AnyLane {
     }
 };
 
+// ---- reference order in the same loops -----------------------------------------------------------------------------
+//
+// src/bvh.cpp:26-59 and :61-86 step by step on the binary tree: a popped node is fetched; a leaf's triangles are tried
+// without a box test; an interior node is culled with the CURRENT bound and its children are pushed as (first,
+// first + 1), so first + 1 is looked at first.  Nothing is reordered or left out: per ray this is closest_exact_t /
+// any_exact_t, only the lanes of a wave take their box steps and their triangle steps together and finished lanes are
+// refilled.
+constexpr uint32_t kNoNode = 0xffffffffu;
+
+struct ExactClosestLane {
+    typedef Stack StackT;
+    static constexpr int kSpillWords = kSpillDepth;
+    static constexpr bool kReferenceOrder = true;
+    RayPre pre;
+    float max_dis;
+    HitD hit;
+    uint32_t cur;                      // binary node to fetch next, or kNoNode
+    uint32_t leaf_first, leaf_count;   // the leaf the lane stands on (count != 0)
+
+    PTD void idle() {
+        cur = kNoNode;
+        leaf_count = 0u;
+        hit = HitD{-1, 0.0f, 0.0f, 0.0f};
+    }
+    PTD void begin(const DevScene&, const RayD& ray, const RayPre& p) {
+        pre = p;
+        max_dis = ray.tmax;
+        hit = HitD{-1, 0.0f, 0.0f, 0.0f};
+        cur = 0u;
+        leaf_first = leaf_count = 0u;
+    }
+    PTD bool box_ready() const { return leaf_count == 0u && cur != kNoNode; }
+    PTD bool leaf_ready() const { return leaf_count != 0u; }
+    PTD bool finished() const { return leaf_count == 0u && cur == kNoNode; }
+    PTD void next(Stack& st) { cur = st.empty() ? kNoNode : st.pop(); }
+
+    template <class C>
+    PTD void inner(const DevScene& sc, Stack& st, C& wc) {
+        wc.node();
+        const float4 n0 = sc.nodes[2 * size_t(cur)];
+        const float4 n1 = sc.nodes[2 * size_t(cur) + 1];
+        const uint32_t first = as_u(n1.z), count = as_u(n1.w);
+        if (count != 0u) {
+            leaf_first = first;
+            leaf_count = count;
+            return;
+        }
+        const BoxT b = box_decide<false>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, pre);
+        if (b.overlap && b.tn < max_dis) {
+            st.push(first);
+            cur = first + 1u;
+        } else {
+            next(st);
+        }
+    }
+    template <class C>
+    PTD void leaf(const DevScene& sc, Stack& st, C& wc) {
+        for (uint32_t k = 0; k < leaf_count; ++k) {
+            V3 p0, e1, e2;
+            int32_t prim;
+            load_tri(sc, leaf_first + k, p0, e1, e2, prim);
+            wc.tri();
+            float t, u, v;
+            if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, max_dis, t, u, v)) {
+                max_dis = t;
+                hit = HitD{prim, t, u, v};
+            }
+        }
+        leaf_count = 0u;
+        next(st);
+    }
+    PTD bool redo() const { return false; }
+    PTD float redo_bound() const { return 0.0f; }
+};
+
+struct ExactAnyLane {
+    typedef Stack StackT;
+    static constexpr int kSpillWords = kSpillDepth;
+    static constexpr bool kReferenceOrder = true;
+    RayPre pre;
+    float tmax;
+    bool occluded;
+    uint32_t cur, leaf_first, leaf_count;
+
+    PTD void idle() {
+        cur = kNoNode;
+        leaf_count = 0u;
+        occluded = false;
+    }
+    PTD void begin(const DevScene&, const RayD& ray, const RayPre& p) {
+        pre = p;
+        tmax = ray.tmax;
+        occluded = false;
+        cur = 0u;
+        leaf_first = leaf_count = 0u;
+    }
+    PTD bool box_ready() const { return leaf_count == 0u && cur != kNoNode; }
+    PTD bool leaf_ready() const { return leaf_count != 0u; }
+    PTD bool finished() const { return leaf_count == 0u && cur == kNoNode; }
+    PTD void next(Stack& st) { cur = st.empty() ? kNoNode : st.pop(); }
+
+    template <class C>
+    PTD void inner(const DevScene& sc, Stack& st, C& wc) {
+        wc.node();
+        const float4 n0 = sc.nodes[2 * size_t(cur)];
+        const float4 n1 = sc.nodes[2 * size_t(cur) + 1];
+        const uint32_t first = as_u(n1.z), count = as_u(n1.w);
+        if (count != 0u) {
+            leaf_first = first;
+            leaf_count = count;
+            return;
+        }
+        const BoxT b = box_decide<false>(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, pre);
+        if (b.overlap && b.tn < tmax) {
+            st.push(first);
+            cur = first + 1u;
+        } else {
+            next(st);
+        }
+    }
+    template <class C>
+    PTD void leaf(const DevScene& sc, Stack& st, C& wc) {
+        for (uint32_t k = 0; k < leaf_count; ++k) {
+            V3 p0, e1, e2;
+            int32_t prim;
+            load_tri(sc, leaf_first + k, p0, e1, e2, prim);
+            wc.tri();
+            float t, u, v;
+            if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, tmax, t, u, v)) {
+                occluded = true;
+                leaf_count = 0u;
+                cur = kNoNode;
+                return;
+            }
+        }
+        leaf_count = 0u;
+        next(st);
+    }
+};
+
+// Deferred-ray marker of the reference-order kernels (the ordered ones put a distance bound >= 0 or +inf there): the
+// follow-up pass traces the ray with the plain reference-order routine.
+constexpr float kDeferExact = -1.0f;
+
 // lane states of the shared loop
 constexpr int kLaneEmpty = 0, kLaneBusy = 1, kLaneDone = 2;
 
@@ -204,15 +375,14 @@ PTD uint32_t wave_fetch(bool want, uint32_t* counter, uint32_t count, bool& more
 //                                                           false = position j holds no query (reported as a miss)
 //   void commit(sc, shard, fin, j, hit, defer, bound, carry, o, d)   called by the whole wave; fin marks lanes with a result
 // lds_stack: this lane's column of a [2 * kDistRows][kBlock] array of words.
-template <class Io, class C>
+template <class Lane, class Io, class C>
 PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, C& wc) {
     const uint32_t count = io.count(shard);
-    uint32_t spill[2 * kDistSpill];
-    DistStack st;
+    uint32_t spill[Lane::kSpillWords];
+    typename Lane::StackT st;
     st.init(lds_stack, spill);
-    ClosestLane L;
-    L.cur = kDone;
-    L.hit = HitD{-1, 0.0f, 0.0f, 0.0f};
+    Lane L;
+    L.idle();
     typename Io::Carry carry{};
     uint32_t j = 0;
     int state = kLaneEmpty;
@@ -239,7 +409,7 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
                 } else if (pre.special) {
                     state = kLaneDone;
                     defer = true;
-                    bound = __builtin_huge_valf();
+                    bound = Lane::kReferenceOrder ? kDeferExact : __builtin_huge_valf();
                     L.hit.prim = -1;
                 } else {
                     L.begin(sc, ray, pre);
@@ -256,14 +426,14 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
         const uint32_t low = more ? kRefillBelow : 1u;
         for (;;) {
             for (;;) {
-                const bool inner = state == kLaneBusy && !(L.cur >> 31);
+                const bool inner = state == kLaneBusy && L.box_ready();
                 const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
                 if (n_inner == 0u) break;
                 if (inner) L.inner(sc, st, wc);
                 if (n_inner < kMinBoxLanes) break;
             }
-            if (state == kLaneBusy && L.cur > kDone) L.leaf(sc, st, wc);
-            if (state == kLaneBusy && L.cur == kDone) {
+            if (state == kLaneBusy && L.leaf_ready()) L.leaf(sc, st, wc);
+            if (state == kLaneBusy && L.finished()) {
                 state = kLaneDone;
                 defer = L.redo();
                 bound = L.redo_bound();
@@ -275,15 +445,14 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
 
 // Any hit for the rays of one shard.  Io: count(shard), load(sc, shard, j, RayD&, Carry&),
 // commit(sc, shard, fin, j, occluded, defer, carry) -- per lane, no wave-level operation required.
-template <class Io, class C>
+template <class Lane, class Io, class C>
 PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, C& wc) {
     const uint32_t count = io.count(shard);
-    uint32_t spill[kSpillDepth];
-    Stack st;
+    uint32_t spill[Lane::kSpillWords];
+    typename Lane::StackT st;
     st.init(lds_stack, spill);
-    AnyLane L;
-    L.cur = kDone;
-    L.occluded = false;
+    Lane L;
+    L.idle();
     typename Io::Carry carry{};
     uint32_t j = 0;
     int state = kLaneEmpty;
@@ -319,14 +488,14 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
         const uint32_t low = more ? kRefillBelow : 1u;
         for (;;) {
             for (;;) {
-                const bool inner = state == kLaneBusy && !(L.cur >> 31);
+                const bool inner = state == kLaneBusy && L.box_ready();
                 const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
                 if (n_inner == 0u) break;
                 if (inner) L.inner(sc, st, wc);
                 if (n_inner < kMinBoxLanes) break;
             }
-            if (state == kLaneBusy && L.cur > kDone) L.leaf(sc, st, wc);
-            if (state == kLaneBusy && L.cur == kDone) state = kLaneDone;
+            if (state == kLaneBusy && L.leaf_ready()) L.leaf(sc, st, wc);
+            if (state == kLaneBusy && L.finished()) state = kLaneDone;
             if (uint32_t(__popcll(__ballot(state == kLaneBusy))) < low) break;
         }
     }
