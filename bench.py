@@ -156,8 +156,8 @@ def main():
         # read from inside this process); the committed figure is quoted when it is for this workload and kernel
         traffic, traffic_note, counters = None, None, None
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s/%s" % (a.workload, a.traversal))
-            if t and t["kernel"] == "k_" + dominant and t["bytes_per_launch"]:
+            t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s/%s" % (a.workload, a.traversal), {}).get("k_" + dominant)
+            if t and t["bytes_per_launch"]:
                 traffic, traffic_note = t["bytes_per_launch"], "%s; %s" % (t["source"], t["how"])
                 counters = {k: t[k] for k in ("valu_issue_frac", "lanes_per_valu_inst_frac", "l2_hit_rate") if k in t}
         except (OSError, ValueError, KeyError):

@@ -86,7 +86,7 @@ inline uint64_t frame_index(uint32_t m, uint64_t frame) {
     return index;
 }
 
-constexpr uint64_t kAutoSlots = uint64_t(128) << 20;  // default number of path slots in flight per pass
+constexpr uint64_t kAutoSlots = uint64_t(65535) * 4096;  // default number of path slots in flight per pass: as many shards as one launch holds
 constexpr uint64_t kBytesPerSlot = 224;             // two path queues, hit list, shadow queue, deferred lists, radiance slot
 constexpr int kRing = 4;  // counter snapshots in flight between the stream and the host
 
@@ -945,7 +945,8 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         // Automatic: as many samples per pixel in flight as fit kAutoSlots path slots (224 B of queue space each).  Every
         // pass ends in a tail of a dozen nearly empty bounces whose cost does not depend on the pass size, so larger
         // passes are faster (measured at 1280x720: 8 M slots 1.5, 64 M 2.5, 128 M 2.7, 256 M 2.8 Grays/s on a 1.6 M
-        // triangle interior); 128 M slots are 27 GB of the 288 GB.  Less when the device is short of memory.
+        // triangle interior; with the later kernels 128 M 3.5, 236 M 3.7); 268 M slots are 60 GB of the 288 GB.  Less when
+        // the device is short of memory.
         uint64_t slots = kAutoSlots;
         if (s->ws.cap_slots < slots) {
             size_t free_b = 0, total_b = 0;
