@@ -10,8 +10,9 @@ pairs = [("%s_bench_%s.json" % (tag, k), "r1_%s_bench_%s.json" % (new, k)) for k
 pairs += [("%s_prof_bench_library_fast.txt" % tag, "r1_%s_rocprof_bench_library_fast.txt" % new),
           ("%s_prof_library_fast.txt" % tag, "r1_%s_rocprof_pmc_library256spp_fast.txt" % new),
           ("%s_prof_veach_fast.txt" % tag, "r1_%s_rocprof_pmc_veach256spp_fast.txt" % new)]
-for f in glob.glob(os.path.join(P, "r1_%s_bench_*.json" % old)) + glob.glob(os.path.join(P, "r1_%s_rocprof_*.txt" % old)):
-    os.remove(f)
+if old != new:
+    for f in glob.glob(os.path.join(P, "r1_%s_bench_*.json" % old)) + glob.glob(os.path.join(P, "r1_%s_rocprof_*.txt" % old)):
+        os.remove(f)
 for a, b in pairs:
     shutil.copy(os.path.join(G, a), os.path.join(P, b))
 
