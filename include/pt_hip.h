@@ -132,7 +132,7 @@ typedef struct pt_render_params {
     uint32_t max_bounce;       /* 32 in the reference (src/integrator.cpp:50); 0 selects 32 */
     int32_t  integrator;       /* PT_INTEGRATOR_* */
     int32_t  traversal;        /* PT_TRAVERSE_* */
-    uint32_t samples_per_pass; /* samples of every pixel in flight at once; 0 = automatic (up to 268 M paths, 60 GB of queues) */
+    uint32_t samples_per_pass; /* samples of every pixel in flight at once; 0 = automatic (up to 537 M paths, 120 GB of queues) */
     uint32_t flags;            /* PT_FLAG_* */
     /* Image split across processes: with block_count > 1 the call renders only the 32x32 pixel blocks (the unit of the
      * reference's BlockGenerator, include/pt/block.h:17, src/block.cpp:116-158) whose column + row index is congruent

@@ -96,6 +96,9 @@ constexpr uint32_t kMaxWaveBlocks = 8;  // workgroups per shard of the wave-refi
 constexpr uint32_t kMinWaveBlocks = 2;
 constexpr uint32_t kShadeBlocks = 8;  // most workgroups per shard of k_shade (256 threads each), see shade_blocks()
 
+// Shards are spread over grid.y and grid.z (grid.y alone ends at 65535).
+PTD uint32_t shard_index() { return blockIdx.z * gridDim.y + blockIdx.y; }
+
 struct PassArgs {
     const uint32_t* frame_tab;  // [frame_local][1024] Sobol' words of the sample numbers of this pass
     uint32_t spp_pass;          // samples per pixel in this pass
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE
                                                                                                                   uint32_t* fetch, uint32_t* done,
                                                                                                                   uint32_t* misc) {
     __shared__ uint32_t s_stack[kWaveRows * kBlock];
-    const uint32_t shard = blockIdx.y;
+    const uint32_t shard = shard_index();
     C wc;
     closest_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
     if (last_block_of_shard(done, shard)) {
@@ -467,7 +470,7 @@ template <class C, class Lane>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_extend_wave(DevScene sc, ExtendIo io, uint32_t* fetch,
                                                                                                     uint32_t* done, ZeroList zl, uint32_t* misc) {
     __shared__ uint32_t s_stack[kWaveRows * kBlock];
-    const uint32_t shard = blockIdx.y;
+    const uint32_t shard = shard_index();
     zero_counters(zl, shard);
     C wc;
     closest_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
@@ -513,7 +516,7 @@ template <class C, class Lane>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_shadow_wave(DevScene sc, ShadowIo io, uint32_t* fetch,
                                                                                                     uint32_t* done, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
-    const uint32_t shard = blockIdx.y;
+    const uint32_t shard = shard_index();
     C wc;
     any_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
     if (last_block_of_shard(done, shard)) {  // plain-division rays of the shard
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded_fix(DevScene sc, const floa
 // shading record and the Sobol' window (all addressed from the entry); (3) the record of the light chosen by the first
 // Sobol' value.
 __global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq, PathQ in, PathQ out, ShadowQ sh, float4* lbuf, ZeroList zl) {
-    const uint32_t shard = blockIdx.y;
+    const uint32_t shard = shard_index();
     zero_counters(zl, shard);
     const size_t sbase = size_t(shard) * kShard;
     const uint32_t n = hq.count[shard];

@@ -27,6 +27,12 @@ int g_device = -1;
 hipStream_t g_stream = nullptr;
 
 constexpr uint32_t kMaxGridY = 65535;
+constexpr uint32_t kMaxGridZ = 8;  // shards of a pass: up to kMaxGridZ * kMaxGridY (2^31 slots would be 524288 shards)
+// launch geometry (workgroups per shard, shards); n_shards is a multiple of its grid.z by construction (ws_reserve)
+inline dim3 shard_grid(uint32_t per_shard, uint32_t n_shards) {
+    const uint32_t gz = (n_shards + kMaxGridY - 1) / kMaxGridY;
+    return dim3(per_shard, n_shards / gz, gz);
+}
 
 int fail(int code, const std::string& msg) {
     g_error = msg;
@@ -86,7 +92,7 @@ inline uint64_t frame_index(uint32_t m, uint64_t frame) {
     return index;
 }
 
-constexpr uint64_t kAutoSlots = uint64_t(65535) * 4096;  // default number of path slots in flight per pass: as many shards as one launch holds
+constexpr uint64_t kAutoSlots = uint64_t(2) * 65535 * 4096;  // default number of path slots in flight per pass (120 GB of queues)
 constexpr uint64_t kBytesPerSlot = 224;             // two path queues, hit list, shadow queue, deferred lists, radiance slot
 constexpr int kRing = 4;  // counter snapshots in flight between the stream and the host
 
@@ -408,8 +414,10 @@ void ws_release(Workspace& ws) {
 }
 
 int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
-    const uint32_t n_shards = (n_slots + kShard - 1) / kShard;
-    if (n_shards > kMaxGridY) return fail(PT_ERR_LIMIT, "too many samples in flight for one pass: lower samples_per_pass");
+    uint32_t n_shards = (n_slots + kShard - 1) / kShard;
+    const uint32_t gz = (n_shards + kMaxGridY - 1) / kMaxGridY;
+    if (gz > kMaxGridZ) return fail(PT_ERR_LIMIT, "too many samples in flight for one pass: lower samples_per_pass");
+    n_shards = (n_shards + gz - 1) / gz * gz;  // whole grid.z layers; the extra shards stay empty
     const uint32_t padded = n_shards * kShard;
     if (padded > ws.cap_slots || n_frames > ws.frame_cap) {
         ws_release(ws);
@@ -536,7 +544,7 @@ int launch_generate(pt_hip_scene* s, const PassArgs& pa, Timer& tm, bool count) 
         // the extend kernel's fetch / deferred / done counters are free until the first extend (zeroed above, and again by
         // the first shade)
         const GenerateIo io{pa, ws.q[0], ws.hq, ws.dqe, ws.lbuf};
-        const dim3 grid(wave_blocks(ws.n_shards, pa.n_slots), ws.n_shards);
+        const dim3 grid = shard_grid(wave_blocks(ws.n_shards, pa.n_slots), ws.n_shards);
         if (count)
             hipLaunchKernelGGL((k_generate_wave<Count, ClosestLane>), grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_e, ws.done_e, ws.misc);
         else
@@ -607,7 +615,7 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
         HitQ hq_next = ws.hq;
         hq_next.count = ws.hit_count[nxt];
         if (int rc = tm.begin(PT_K_SHADE)) return rc;
-        hipLaunchKernelGGL(k_shade, dim3(shade_blocks(K, bound), K), dim3(256), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.q[nxt], ws.sh, ws.lbuf,
+        hipLaunchKernelGGL(k_shade, shard_grid(shade_blocks(K, bound), K), dim3(256), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.q[nxt], ws.sh, ws.lbuf,
                            ZeroList{{hq_next.count, ws.fetch_e, ws.dqe.count, ws.done_e, nullptr}});
         if (int rc = tm.end()) return rc;
         HIP_TRY(hipMemcpyAsync(ws.h_counters + size_t(launched % kRing) * snap, ws.counters, snap * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
@@ -615,7 +623,7 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
         ++launched;
         {
             if (int rc = tm.begin(PT_K_SHADOW)) return rc;
-            const dim3 grid(wave_blocks(K, bound), K);
+            const dim3 grid = shard_grid(wave_blocks(K, bound), K);
             const ShadowIo io{ws.sh, ws.dqs, ws.lbuf};
             if (fast && count)
                 hipLaunchKernelGGL((k_shadow_wave<Count, AnyLane>), grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_s, ws.done_s, ws.misc);
@@ -631,7 +639,7 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
             // clears what the NEXT bounce's shade and shadow accumulate into (this bounce's shadow kernel is done with them)
             const ZeroList zl{{ws.q[cur].count, ws.sh.count, ws.fetch_s, ws.dqs.count, ws.done_s}};
             if (int rc = tm.begin(PT_K_EXTEND)) return rc;
-            const dim3 grid(wave_blocks(K, bound), K);
+            const dim3 grid = shard_grid(wave_blocks(K, bound), K);
             const ExtendIo io{ws.q[nxt], hq_next, ws.dqe};
             if (fast && count)
                 hipLaunchKernelGGL((k_extend_wave<Count, ClosestLane>), grid, dim3(kBlock), 0, g_stream, s->dev, io, ws.fetch_e, ws.done_e, zl, ws.misc);
@@ -945,8 +953,8 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         // Automatic: as many samples per pixel in flight as fit kAutoSlots path slots (224 B of queue space each).  Every
         // pass ends in a tail of a dozen nearly empty bounces whose cost does not depend on the pass size, so larger
         // passes are faster (measured at 1280x720: 8 M slots 1.5, 64 M 2.5, 128 M 2.7, 256 M 2.8 Grays/s on a 1.6 M
-        // triangle interior; with the later kernels 128 M 3.5, 236 M 3.7); 268 M slots are 60 GB of the 288 GB.  Less when
-        // the device is short of memory.
+        // triangle interior; with the later kernels 128 M 3.5, 236 M 3.7, 472 M 3.8); 537 M slots are 120 GB of the 288 GB.
+        // Less when the device is short of memory.
         uint64_t slots = kAutoSlots;
         if (s->ws.cap_slots < slots) {
             size_t free_b = 0, total_b = 0;

@@ -431,8 +431,8 @@ def test_error_reporting(veach_gpu):
         veach_gpu.intersect(np.zeros((4, 8), np.float32), mode=7)
     with pytest.raises(api.PtError):
         veach_gpu.li(np.array([[5000, 1]]), np.array([0]))
-    with pytest.raises(api.PtError, match="lower samples_per_pass"):      # 400 x 921 600 slots: more shards than one launch holds
-        veach_gpu.render(0, 400, samples_per_pass=400)
+    with pytest.raises(api.PtError, match="samples_per_pass too large"):  # 3000 x 921 600 slots: beyond 2^31
+        veach_gpu.render(0, 3000, samples_per_pass=3000)
     with pytest.raises(api.PtError, match="max_bounce"):
         veach_gpu.render(0, 1, max_bounce=64)
     film, st = veach_gpu.render(0, 1)                                     # the handle is still usable after errors

@@ -14,7 +14,7 @@ timeout -k 10 300 python -u bench.py --traversal exact --spp 256 --no-cpu-baseli
 mkdir -p $O/prof_${TAG}_bench
 (cd /tmp && export TMPDIR=/tmp && timeout -s KILL 280 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_bench/kt -o kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_${TAG}_bench/kt.log 2>&1) || exit 6
 python3 tools/prof_summary.py $O/prof_${TAG}_bench > $O/${TAG}_prof_bench_library_fast.txt || exit 7
-bash tools/gpu_prof.sh ${TAG}_library --workload library-synth --spp 256 --traversal fast || exit 8
+bash tools/gpu_prof.sh ${TAG}_library --workload library-synth --spp 512 --traversal fast || exit 8
 python3 tools/prof_summary.py $O/prof_${TAG}_library > $O/${TAG}_prof_library_fast.txt || exit 9
-bash tools/gpu_prof.sh ${TAG}_veach --workload veach-mis --spp 256 --traversal fast || exit 10
+bash tools/gpu_prof.sh ${TAG}_veach --workload veach-mis --spp 512 --traversal fast || exit 10
 python3 tools/prof_summary.py $O/prof_${TAG}_veach > $O/${TAG}_prof_veach_fast.txt || exit 11

@@ -8,8 +8,8 @@ R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
 pairs = [("%s_bench_%s.json" % (tag, k), "r1_%s_bench_%s.json" % (new, k)) for k in ("library_fast", "veach_fast", "veach_exact", "library_exact")]
 pairs += [("%s_prof_bench_library_fast.txt" % tag, "r1_%s_rocprof_bench_library_fast.txt" % new),
-          ("%s_prof_library_fast.txt" % tag, "r1_%s_rocprof_pmc_library256spp_fast.txt" % new),
-          ("%s_prof_veach_fast.txt" % tag, "r1_%s_rocprof_pmc_veach256spp_fast.txt" % new)]
+          ("%s_prof_library_fast.txt" % tag, "r1_%s_rocprof_pmc_library512spp_fast.txt" % new),
+          ("%s_prof_veach_fast.txt" % tag, "r1_%s_rocprof_pmc_veach512spp_fast.txt" % new)]
 if old != new:
     for f in glob.glob(os.path.join(P, "r1_%s_bench_*.json" % old)) + glob.glob(os.path.join(P, "r1_%s_rocprof_*.txt" % old)):
         os.remove(f)
@@ -32,8 +32,8 @@ def calls(path, kern):
 
 
 t = {}
-for key, name, note in (("library-synth/fast", "library256spp", "gathers of 64-B lines are outside the guide's calibration (may read up to 2x low)"),
-                        ("veach-mis/fast", "veach256spp", "the whole scene (0.3 MB of nodes and triangles) lives in L2, what reaches the fabric is queue traffic")):
+for key, name, note in (("library-synth/fast", "library512spp", "gathers of 64-B lines are outside the guide's calibration (may read up to 2x low)"),
+                        ("veach-mis/fast", "veach512spp", "the whole scene (0.3 MB of nodes and triangles) lives in L2, what reaches the fabric is queue traffic")):
     rel = "profiles/r1_%s_rocprof_pmc_%s_fast.txt" % (new, name)
     path = os.path.join(R, rel)
     t[key] = {}
@@ -43,7 +43,7 @@ for key, name, note in (("library-synth/fast", "library256spp", "gathers of 64-B
         p1, p2 = row(path, "pmc1", sym), row(path, "pmc2", sym)
         t[key][kern] = {
             "bytes_per_launch": int((v[2] + v[3]) * 64 / n),
-            "how": "(TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum) x 64 B over the %d %s launches of one 256-spp pass (the size of the bench's passes); %s"
+            "how": "(TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum) x 64 B over the %d %s launches of one 512-spp pass (the size of the bench's passes); %s"
                    % (n, sym, note),
             "source": rel,
             # SQ_INSTS_VALU x 4 cycles over the SIMD cycles of the launches (1024 SIMDs at 2.4 GHz); active lanes per VALU instruction
