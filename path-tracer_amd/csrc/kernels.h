@@ -76,9 +76,14 @@ PTD void store_shared(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOM
 PTD uint32_t load_fresh(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // True in every thread of the block that is the last of its shard (gridDim.x blocks per shard) to get here.
+// The deferred-ray records (store_shared) must have reached the coherent level before the shard's `done` count can be
+// seen by a workgroup on another XCD.  A workgroup-scope release fence does not wait for outstanding vector stores on
+// this target, and an agent-scope one would write back the whole L2, so the wave waits for its own memory operations
+// explicitly (vmcnt(0), leaving the other counters alone) before the barrier that precedes the sign-off.
 PTD bool last_block_of_shard(uint32_t* done, uint32_t shard) {
     __shared__ uint32_t s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have completed
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt = 0 (bits 3:0 and 15:14), expcnt and lgkmcnt untouched
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) s_last = (atomicAdd(done + shard, 1u) == gridDim.x - 1u) ? 1u : 0u;
     __syncthreads();
@@ -766,7 +771,10 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq
                     cont = true;
                     na = make_float4(no.x, no.y, no.z, bs.wi.x);
                     nb = make_float4(bs.wi.y, bs.wi.z, T.x, T.y);
-                    nc = make_float4(T.z, newPdf, as_f(pix), as_f(uint32_t(smp.dim) | (uint32_t(bounce) << 10) | (frame << 16)));
+                    // the sampler wraps lazily (dim == 1024 after drawing dimension 1023): store the dimension the next
+                    // draw would wrap to (src/sampler.cpp:102-114), so that it fits the 10-bit field
+                    const uint32_t next_dim = smp.dim >= 1024 ? 2u : uint32_t(smp.dim);
+                    nc = make_float4(T.z, newPdf, as_f(pix), as_f(next_dim | (uint32_t(bounce) << 10) | (frame << 16)));
                 }
             }
         }

@@ -143,6 +143,12 @@ struct pt_hip_scene {
     EventPool events;
     uint32_t* batch_fetch = nullptr;  // per-shard fetch counters of the batched ordered queries
     size_t batch_fetch_cap = 0;
+    // grow-only device staging of the host-pointer entry points (rays, hits, flags, sample lists, film), so that a
+    // caller that renders or queries batch after batch does not pay an allocation per call
+    enum { kStageSlots = 6 };
+    void* stage[kStageSlots] = {};
+    size_t stage_cap[kStageSlots] = {};
+    hipEvent_t query_ev[2] = {};  // start / stop of a batched query
     // image split (pt_render_params::block_count > 1): tile tables of the most recent (rank, count)
     uint32_t* tile_list = nullptr;
     int32_t* tile_pos = nullptr;
@@ -168,6 +174,8 @@ int validate(const pt_scene_desc* d, uint32_t& depth_out) {
     if (d->n_tris == 0 || d->n_nodes == 0) return fail(PT_ERR_INVALID, "scene has no triangles or no BVH nodes");
     if (!d->verts || !d->vi || !d->mat_id || !d->light_id || !d->mats || !d->nodes || !d->prim_ids)
         return fail(PT_ERR_INVALID, "scene description has a null required array");
+    if ((d->n_lights && !d->lights) || (d->n_textures && !d->textures) || (d->n_normals && !d->normals) || (d->n_uvs && !d->uvs))
+        return fail(PT_ERR_INVALID, "scene description has a null array with a non-zero count (lights, textures, normals or uvs)");
     if (d->n_tris > kLeafFirstMask) return fail(PT_ERR_LIMIT, "more than 2^27-1 triangles");
     if (d->camera.width == 0 || d->camera.height == 0 || d->camera.width > 32768 || d->camera.height > 32768)
         return fail(PT_ERR_INVALID, "camera resolution out of range (1..32768)");
@@ -184,8 +192,12 @@ int validate(const pt_scene_desc* d, uint32_t& depth_out) {
     }
     for (uint32_t i = 0; i < d->n_mats; ++i)
         if (d->mats[i].tex >= int32_t(d->n_textures)) return fail(PT_ERR_INVALID, "texture id out of range");
-    for (uint32_t i = 0; i < d->n_lights; ++i)
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
         if (d->lights[i].tri >= d->n_tris) return fail(PT_ERR_INVALID, "light triangle out of range");
+        // zero, negative or NaN: 1/area would put inf or NaN into every radiance value.  +inf is what Triangle::surfaceArea
+        // (src/shape.cpp:32-36) itself returns for astronomically large triangles (its norm overflows); 1/area is then 0.
+        if (!(d->lights[i].area > 0.0f)) return fail(PT_ERR_INVALID, "light with a zero, negative or NaN area");
+    }
     // walk the tree: every node reachable once, ranges in bounds, depth within the traversal stack
     std::vector<std::pair<uint32_t, uint32_t>> stack{{0u, 1u}};
     std::vector<uint8_t> seen(d->n_nodes, 0);
@@ -657,6 +669,24 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
     return PT_OK;
 }
 
+// device staging buffer `slot` of at least `bytes` bytes (contents are not preserved when it grows)
+template <typename T>
+int stage_reserve(pt_hip_scene* s, int slot, size_t bytes, T** out) {
+    if (bytes > s->stage_cap[slot]) {
+        if (s->stage[slot]) {
+            HIP_TRY(hipStreamSynchronize(g_stream));
+            (void)hipFree(s->stage[slot]);
+        }
+        s->stage[slot] = nullptr;
+        s->stage_cap[slot] = 0;
+        const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+        HIP_TRY(hipMalloc(&s->stage[slot], want));
+        s->stage_cap[slot] = want;
+    }
+    *out = static_cast<T*>(s->stage[slot]);
+    return PT_OK;
+}
+
 int check_ready(const pt_hip_scene* s) {
     if (g_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
     if (!s) return fail(PT_ERR_INVALID, "scene handle is null");
@@ -676,17 +706,21 @@ int batch_fetch_reserve(pt_hip_scene* s, uint32_t n_shards) {
     return PT_OK;
 }
 
-int launch_intersect(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_hit* d_hits, int mode) {
+// `fetch`: zeroed per-shard fetch counters for the ordered mode (one per kShard rays); null = the handle's own, grown on demand
+int launch_intersect(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_hit* d_hits, int mode, uint32_t* fetch = nullptr) {
     const float4* rays = reinterpret_cast<const float4*>(d_rays);
     float4* hits = reinterpret_cast<float4*>(d_hits);
     if (mode == PT_TRAVERSE_FAST) {
         const uint32_t n_shards = blocks(uint32_t(n), kShard);
-        if (int rc = batch_fetch_reserve(s, n_shards)) return rc;
+        if (!fetch) {
+            if (int rc = batch_fetch_reserve(s, n_shards)) return rc;
+            fetch = s->batch_fetch;
+        }
         for (uint32_t s0 = 0; s0 < n_shards; s0 += kMaxGridY) {  // grid.y is limited to 65535
             const size_t off = size_t(s0) * kShard;
             const BatchClosestIo io{rays + 2 * off, uint32_t(std::min<size_t>(n - off, size_t(kMaxGridY) * kShard)), hits + off};
             hipLaunchKernelGGL(k_intersect_wave<NoCount>, dim3(wave_blocks(blocks(io.n, kShard), io.n), blocks(io.n, kShard)), dim3(kBlock),
-                               0, g_stream, s->dev, io, s->batch_fetch + s0, (uint32_t*)nullptr);
+                               0, g_stream, s->dev, io, fetch + s0, (uint32_t*)nullptr);
         }
         hipLaunchKernelGGL(k_intersect_fix<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev, rays, uint32_t(n),
                            hits, (uint32_t*)nullptr);
@@ -828,8 +862,19 @@ int pt_hip_scene_destroy(pt_hip_scene* s) {
     ws_release(s->ws);
     for (hipEvent_t e : s->events.ev) (void)hipEventDestroy(e);
     if (s->batch_fetch) (void)hipFree(s->batch_fetch);
+    for (void* p : s->stage)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : s->query_ev)
+        if (e) (void)hipEventDestroy(e);
     for (void* p : s->owned) (void)hipFree(p);
     delete s;
+    return PT_OK;
+}
+
+// start / stop events of a batched query: created once per handle
+static int query_events(pt_hip_scene* s) {
+    for (hipEvent_t& e : s->query_ev)
+        if (!e) HIP_TRY(hipEventCreate(&e));
     return PT_OK;
 }
 
@@ -838,19 +883,15 @@ int pt_hip_intersect_device(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_
     if (mode < 0 || mode > 1) return fail(PT_ERR_INVALID, "unknown traversal mode");
     if (n == 0) return PT_OK;
     if (!d_rays || !d_hits || n > 0xffffffffull) return fail(PT_ERR_INVALID, "bad ray buffer");
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, g_stream));
+    if (int rc = query_events(s)) return rc;
+    HIP_TRY(hipEventRecord(s->query_ev[0], g_stream));
     if (int rc = launch_intersect(s, d_rays, n, d_hits, mode)) return rc;
-    HIP_TRY(hipEventRecord(e1, g_stream));
+    HIP_TRY(hipEventRecord(s->query_ev[1], g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     HIP_TRY(hipGetLastError());
     float ms = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    HIP_TRY(hipEventElapsedTime(&ms, s->query_ev[0], s->query_ev[1]));
     if (kernel_ms) *kernel_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return PT_OK;
 }
 
@@ -859,40 +900,33 @@ int pt_hip_occluded_device(pt_hip_scene* s, const pt_ray* d_rays, size_t n, uint
     if (mode < 0 || mode > 1) return fail(PT_ERR_INVALID, "unknown traversal mode");
     if (n == 0) return PT_OK;
     if (!d_rays || !d_occ || n > 0xffffffffull) return fail(PT_ERR_INVALID, "bad ray buffer");
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, g_stream));
+    if (int rc = query_events(s)) return rc;
+    HIP_TRY(hipEventRecord(s->query_ev[0], g_stream));
     if (int rc = launch_occluded(s, d_rays, n, d_occ, nullptr, mode)) return rc;
-    HIP_TRY(hipEventRecord(e1, g_stream));
+    HIP_TRY(hipEventRecord(s->query_ev[1], g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     HIP_TRY(hipGetLastError());
     float ms = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    HIP_TRY(hipEventElapsedTime(&ms, s->query_ev[0], s->query_ev[1]));
     if (kernel_ms) *kernel_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return PT_OK;
 }
 
 int pt_hip_intersect(pt_hip_scene* s, const pt_ray* rays, size_t n, pt_hit* hits, int mode) {
     if (int rc = check_ready(s)) return rc;
+    if (mode < 0 || mode > 1) return fail(PT_ERR_INVALID, "unknown traversal mode");
     if (n == 0) return PT_OK;
     if (!rays || !hits || n > 0xffffffffull) return fail(PT_ERR_INVALID, "bad ray buffer");
     pt_ray* d_rays = nullptr;
     pt_hit* d_hits = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_rays), n * sizeof(pt_ray)));
-    if (hipMalloc(reinterpret_cast<void**>(&d_hits), n * sizeof(pt_hit)) != hipSuccess) {
-        (void)hipFree(d_rays);
-        return fail(PT_ERR_DEVICE, "hipMalloc failed for the hit buffer");
-    }
-    int rc = PT_OK;
-    if (hipMemcpy(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice) != hipSuccess) rc = fail(PT_ERR_DEVICE, "ray upload failed");
-    if (!rc) rc = pt_hip_intersect_device(s, d_rays, n, d_hits, mode, nullptr);
-    if (!rc && hipMemcpy(hits, d_hits, n * sizeof(pt_hit), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PT_ERR_DEVICE, "hit download failed");
-    (void)hipFree(d_rays);
-    (void)hipFree(d_hits);
-    return rc;
+    if (int rc = stage_reserve(s, 0, n * sizeof(pt_ray), &d_rays)) return rc;
+    if (int rc = stage_reserve(s, 1, n * sizeof(pt_hit), &d_hits)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice, g_stream));
+    if (int rc = launch_intersect(s, d_rays, n, d_hits, mode)) return rc;
+    HIP_TRY(hipMemcpyAsync(hits, d_hits, n * sizeof(pt_hit), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
 }
 
 int pt_hip_occluded(pt_hip_scene* s, const pt_ray* rays, size_t n, uint8_t* occluded, int32_t* first_prim, int mode) {
@@ -903,29 +937,16 @@ int pt_hip_occluded(pt_hip_scene* s, const pt_ray* rays, size_t n, uint8_t* occl
     pt_ray* d_rays = nullptr;
     uint8_t* d_occ = nullptr;
     int32_t* d_first = nullptr;
-    int rc = PT_OK;
-    auto cleanup = [&]() {
-        (void)hipFree(d_rays);
-        (void)hipFree(d_occ);
-        (void)hipFree(d_first);
-    };
-    if (hipMalloc(reinterpret_cast<void**>(&d_rays), n * sizeof(pt_ray)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_occ), n) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_first), n * sizeof(int32_t)) != hipSuccess) {
-        cleanup();
-        return fail(PT_ERR_DEVICE, "hipMalloc failed for the occlusion buffers");
-    }
-    if (hipMemcpy(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice) != hipSuccess) rc = fail(PT_ERR_DEVICE, "ray upload failed");
-    if (!rc) {
-        rc = launch_occluded(s, d_rays, n, d_occ, d_first, mode);
-        if (rc) {
-        } else if (hipStreamSynchronize(g_stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(PT_ERR_DEVICE, "k_occluded failed");
-    }
-    if (!rc && hipMemcpy(occluded, d_occ, n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PT_ERR_DEVICE, "download failed");
-    if (!rc && first_prim && hipMemcpy(first_prim, d_first, n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(PT_ERR_DEVICE, "download failed");
-    cleanup();
-    return rc;
+    if (int rc = stage_reserve(s, 0, n * sizeof(pt_ray), &d_rays)) return rc;
+    if (int rc = stage_reserve(s, 1, n * sizeof(int32_t), &d_first)) return rc;
+    if (int rc = stage_reserve(s, 2, n, &d_occ)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_rays, rays, n * sizeof(pt_ray), hipMemcpyHostToDevice, g_stream));
+    if (int rc = launch_occluded(s, d_rays, n, d_occ, d_first, mode)) return rc;
+    HIP_TRY(hipMemcpyAsync(occluded, d_occ, n, hipMemcpyDeviceToHost, g_stream));
+    if (first_prim) HIP_TRY(hipMemcpyAsync(first_prim, d_first, n * sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
 }
 
 int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float* d_film, pt_stats* st) {
@@ -962,7 +983,7 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
             const uint64_t held = uint64_t(s->ws.cap_slots) * kBytesPerSlot;
             slots = std::min<uint64_t>(slots, (uint64_t(free_b) + held) * 6 / 10 / kBytesPerSlot);
         }
-        spp_pass = uint32_t(std::max<uint64_t>(1, slots / slots_per_sample));
+        spp_pass = uint32_t(std::min<uint64_t>(0xffffu, std::max<uint64_t>(1, slots / slots_per_sample)));  // 16-bit frame field of the path state
     }
     spp_pass = std::min(spp_pass, total_spp);
     if (p.samples_per_pass == 0) {  // automatic: passes of equal size instead of full ones and a small remainder
@@ -974,6 +995,7 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
     if (int rc = ws_reserve(s->ws, uint32_t(slots_per_sample * spp_pass), spp_pass)) return rc;
     Workspace& ws = s->ws;
     HIP_TRY(hipMemsetAsync(d_film, 0, sizeof(float) * 4 * size_t(W + 4) * size_t(H + 4), g_stream));
+    s->events.used = 0;  // an earlier call that failed half-way may have left recorded pairs behind
     Timer tm{s, (p.flags & PT_FLAG_NO_KERNEL_TIMING) == 0};
     const bool count = (p.flags & PT_FLAG_COUNT_WORK) != 0;
     std::vector<uint32_t> frame_words;
@@ -1026,11 +1048,10 @@ int pt_hip_render(pt_hip_scene* s, const pt_render_params* params, float* film, 
     if (!film) return fail(PT_ERR_INVALID, "film pointer is null");
     const size_t bytes = sizeof(float) * 4 * size_t(s->width + 4) * size_t(s->height + 4);
     float* d_film = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_film), bytes));
-    int rc = pt_hip_render_device(s, params, d_film, st);
-    if (!rc && hipMemcpy(film, d_film, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(PT_ERR_DEVICE, "film download failed");
-    (void)hipFree(d_film);
-    return rc;
+    if (int rc = stage_reserve(s, 3, bytes, &d_film)) return rc;
+    if (int rc = pt_hip_render_device(s, params, d_film, st)) return rc;
+    HIP_TRY(hipMemcpy(film, d_film, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
 }
 
 int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pixel_xy, const uint32_t* sample_index, size_t n, float* rgb,
@@ -1064,16 +1085,9 @@ int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pi
     int32_t* d_xy = nullptr;
     uint32_t* d_fl = nullptr;
     float* d_ps = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(d_xy);
-        (void)hipFree(d_fl);
-        (void)hipFree(d_ps);
-    };
-    if (hipMalloc(reinterpret_cast<void**>(&d_xy), n * 8) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&d_fl), n * 4) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&d_ps), n * 8) != hipSuccess) {
-        cleanup();
-        return fail(PT_ERR_DEVICE, "hipMalloc failed for the sample list");
-    }
+    if (int r = stage_reserve(s, 0, n * 8, &d_xy)) return r;
+    if (int r = stage_reserve(s, 1, n * 4, &d_fl)) return r;
+    if (int r = stage_reserve(s, 2, n * 8, &d_ps)) return r;
     int rc = PT_OK;
     auto run = [&]() -> int {
         HIP_TRY(hipMemcpy(d_xy, pixel_xy, n * 8, hipMemcpyHostToDevice));
@@ -1089,7 +1103,8 @@ int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pi
         pa.list_xy = d_xy;
         pa.list_frame = d_fl;
         pa.list_pixel_sample = d_ps;
-        Timer tm{s, true};
+        s->events.used = 0;
+        Timer tm{s, (p.flags & PT_FLAG_NO_KERNEL_TIMING) == 0};
         const bool count = (p.flags & PT_FLAG_COUNT_WORK) != 0;
         if (int r = launch_generate(s, pa, tm, count)) return r;
         if (st) {
@@ -1111,7 +1126,6 @@ int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pi
         return PT_OK;
     };
     rc = run();
-    cleanup();
     if (st) st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return rc;
 }
@@ -1155,15 +1169,12 @@ int pt_hip_sobol(pt_hip_scene* s, const int32_t* pixel_xy, const uint32_t* sampl
         sobol_words_all_dims(idx, frame_words.data() + size_t(kv.second) * 1024);
     }
     void *d_tab = nullptr, *d_xy = nullptr, *d_fl = nullptr, *d_dim = nullptr, *d_out = nullptr;
-    auto cleanup = [&]() {
-        for (void* p : {d_tab, d_xy, d_fl, d_dim, d_out}) (void)hipFree(p);
-    };
+    if (int r = stage_reserve(s, 0, n * 8, &d_xy)) return r;
+    if (int r = stage_reserve(s, 1, n * 4, &d_fl)) return r;
+    if (int r = stage_reserve(s, 2, n * 4, &d_dim)) return r;
+    if (int r = stage_reserve(s, 4, n * 4, &d_out)) return r;
+    if (int r = stage_reserve(s, 5, frame_words.size() * 4, &d_tab)) return r;
     auto run = [&]() -> int {
-        HIP_TRY(hipMalloc(&d_tab, frame_words.size() * 4));
-        HIP_TRY(hipMalloc(&d_xy, n * 8));
-        HIP_TRY(hipMalloc(&d_fl, n * 4));
-        HIP_TRY(hipMalloc(&d_dim, n * 4));
-        HIP_TRY(hipMalloc(&d_out, n * 4));
         HIP_TRY(hipMemcpy(d_tab, frame_words.data(), frame_words.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_xy, pixel_xy, n * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_fl, frame_local.data(), n * 4, hipMemcpyHostToDevice));
@@ -1176,9 +1187,7 @@ int pt_hip_sobol(pt_hip_scene* s, const int32_t* pixel_xy, const uint32_t* sampl
         HIP_TRY(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
         return PT_OK;
     };
-    const int rc = run();
-    cleanup();
-    return rc;
+    return run();
 }
 
 }  // extern "C"
