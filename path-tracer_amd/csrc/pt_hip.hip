@@ -34,6 +34,15 @@ inline dim3 shard_grid(uint32_t per_shard, uint32_t n_shards) {
     return dim3(per_shard, n_shards / gz, gz);
 }
 
+// Fetch counters of pt_hip_intersect_device_noalloc: one word per shard of kShard rays, in the library's own image so
+// that the entry point needs no allocation.  Every GPU holds its own copy at its own address; host code must use the
+// per-device address that pt_hip_init obtains with hipGetSymbolAddress (g_noalloc_fetch), never this name.
+constexpr uint32_t kNoAllocShards = PT_NOALLOC_MAX_RAYS / kShard;
+static_assert(kNoAllocShards * kShard == PT_NOALLOC_MAX_RAYS && kNoAllocShards <= kMaxGridY, "whole shards, one launch");
+static __device__ __align__(256) uint32_t scratch[kNoAllocShards];
+constexpr int kMaxDevices = 64;
+uint32_t* g_noalloc_fetch[kMaxDevices] = {};
+
 int fail(int code, const std::string& msg) {
     g_error = msg;
     return code;
@@ -827,6 +836,11 @@ int pt_hip_init(int device_ordinal) {
         g_stream = nullptr;
     }
     if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (device_ordinal < kMaxDevices && !g_noalloc_fetch[device_ordinal]) {  // this device's copy of the static fetch counters
+        uint32_t* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch)));
+        g_noalloc_fetch[device_ordinal] = p;
+    }
     g_device = device_ordinal;
     return PT_OK;
 }
@@ -909,6 +923,24 @@ int pt_hip_occluded_device(pt_hip_scene* s, const pt_ray* d_rays, size_t n, uint
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, s->query_ev[0], s->query_ev[1]));
     if (kernel_ms) *kernel_ms = ms;
+    return PT_OK;
+}
+
+int pt_hip_intersect_device_noalloc(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_hit* d_hits, int mode) {
+    if (int rc = check_ready(s)) return rc;
+    if (mode < 0 || mode > 1) return fail(PT_ERR_INVALID, "unknown traversal mode");
+    if (n == 0) return PT_OK;
+    if (!d_rays || !d_hits) return fail(PT_ERR_INVALID, "bad ray buffer");
+    if (n > PT_NOALLOC_MAX_RAYS)
+        return fail(PT_ERR_LIMIT, "pt_hip_intersect_device_noalloc takes at most " + std::to_string(PT_NOALLOC_MAX_RAYS) + " rays per call (" +
+                                      std::to_string(n) + " given): split the batch or use pt_hip_intersect_device");
+    uint32_t* fetch = g_device < kMaxDevices ? g_noalloc_fetch[g_device] : nullptr;
+    if (!fetch) return fail(PT_ERR_NOT_INIT, "no static work buffer on this device (device ordinal beyond " + std::to_string(kMaxDevices - 1) + ")");
+    // the buffer keeps the previous call's counters: clear the part this call uses
+    if (mode == PT_TRAVERSE_FAST) HIP_TRY(hipMemsetAsync(fetch, 0, size_t(blocks(uint32_t(n), kShard)) * sizeof(uint32_t), g_stream));
+    if (int rc = launch_intersect(s, d_rays, n, d_hits, mode, fetch)) return rc;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipGetLastError());
     return PT_OK;
 }
 

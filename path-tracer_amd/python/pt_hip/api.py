@@ -13,6 +13,7 @@ LIB_DIR = os.environ.get("PT_HIP_LIB_DIR") or os.path.join(_PKG, "lib")   # wher
 TRAVERSE_EXACT, TRAVERSE_FAST = 0, 1
 FLAG_NO_KERNEL_TIMING, FLAG_COUNT_WORK = 1, 2
 INTEGRATOR_PATH, INTEGRATOR_NORMAL, INTEGRATOR_ALBEDO = 0, 1, 2
+NOALLOC_MAX_RAYS = 67108864      # PT_NOALLOC_MAX_RAYS
 KERNEL_NAMES = ["generate", "extend", "shade", "shadow", "film", "retrace", "k6", "k7"]
 
 c_f32p = C.POINTER(C.c_float)
@@ -113,6 +114,7 @@ def hip_lib():
         L.pt_hip_occluded.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, c_u8p, c_i32p, C.c_int]
         L.pt_hip_intersect_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, c_f32p]
         L.pt_hip_occluded_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, c_f32p]
+        L.pt_hip_intersect_device_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.pt_hip_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), c_f32p, C.POINTER(Stats)]
         L.pt_hip_render_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
         L.pt_hip_li.argtypes = [C.c_void_p, C.POINTER(RenderParams), c_i32p, c_u32p, C.c_size_t, c_f32p, c_f32p, C.POINTER(Stats)]
@@ -259,6 +261,16 @@ class Scene:
         hits = np.zeros(len(rays), HIT_DTYPE)
         _chk(hip_lib().pt_hip_intersect(self.h, rays.ctypes.data, len(rays), hits.ctypes.data, mode))
         return hits
+
+    def intersect_device(self, d_rays_ptr, n, d_hits_ptr, mode=TRAVERSE_FAST, noalloc=False):
+        """Closest hits of n pt_ray records at device address d_rays_ptr into n pt_hit records at d_hits_ptr.  noalloc=True
+        takes the entry point that allocates nothing (at most NOALLOC_MAX_RAYS rays); returns the kernel time in ms or None."""
+        if noalloc:
+            _chk(hip_lib().pt_hip_intersect_device_noalloc(self.h, C.c_void_p(d_rays_ptr), n, C.c_void_p(d_hits_ptr), mode))
+            return None
+        ms = C.c_float(0.0)
+        _chk(hip_lib().pt_hip_intersect_device(self.h, C.c_void_p(d_rays_ptr), n, C.c_void_p(d_hits_ptr), mode, C.byref(ms)))
+        return ms.value
 
     def occluded(self, rays, mode=TRAVERSE_EXACT):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
