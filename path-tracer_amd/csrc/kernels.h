@@ -589,7 +589,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect_fix(DevScene sc, const flo
             const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
             HitD h;
             bool redo = true;
-            if (m.y == __builtin_huge_valf()) {
+            if (m.y == kDeferExact) {
+                closest_exact(sc, ray, h, s_stack + threadIdx.x, wc);
+            } else if (m.y == __builtin_huge_valf()) {
                 closest_fast(sc, ray, h, redo, s_stack + threadIdx.x, wc);
             } else {
                 const RayPre pre = make_pre(sc, ray);

@@ -235,12 +235,26 @@ int validate(const pt_scene_desc* d, uint32_t& depth_out) {
 
 int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     DevScene& dev = s->dev;
+    // Leaf array: every leaf is a header record (its parent's box, see leaf_parent_accepts) followed by its triangles
+    // {p0, prim} {e1} {e2}; slot_of[i] = header slot of leaf node i.
+    std::vector<uint32_t> slot_of(d->n_nodes, 0), parent(d->n_nodes, 0);
+    uint32_t n_slots = 0;
+    for (uint32_t i = 0; i < d->n_nodes; ++i) {
+        const pt_bvh_node& b = d->nodes[i];
+        if (b.count) {
+            slot_of[i] = n_slots;
+            n_slots += 1u + b.count;
+        } else {
+            parent[b.first] = parent[b.first + 1] = i;
+        }
+    }
+    if (n_slots > kLeafFirstMask) return fail(PT_ERR_LIMIT, "triangles + leaves exceed 2^27-1 leaf-array records");
     // reference-order nodes
     {
         std::vector<float4> n(2 * size_t(d->n_nodes));
         for (uint32_t i = 0; i < d->n_nodes; ++i) {
             const pt_bvh_node& b = d->nodes[i];
-            uint32_t first = b.first, count = b.count;
+            uint32_t first = b.count ? slot_of[i] + 1u : b.first, count = b.count;
             float ff, fc;
             std::memcpy(&ff, &first, 4);
             std::memcpy(&fc, &count, 4);
@@ -249,19 +263,31 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
         }
         if (int rc = upload(s, n.data(), n.size(), &dev.nodes)) return rc;
     }
-    // triangles in leaf order
     {
-        std::vector<float4> t(3 * size_t(d->n_tris));
-        for (uint32_t k = 0; k < d->n_tris; ++k) {
-            const uint32_t prim = d->prim_ids[k];
-            const float* p0 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 0] - 1);
-            const float* p1 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 1] - 1);
-            const float* p2 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 2] - 1);
-            float fp;
-            std::memcpy(&fp, &prim, 4);
-            t[3 * size_t(k) + 0] = make_float4(p0[0], p0[1], p0[2], fp);
-            t[3 * size_t(k) + 1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.0f);
-            t[3 * size_t(k) + 2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f);
+        std::vector<float4> t(3 * size_t(n_slots));
+        for (uint32_t i = 0; i < d->n_nodes; ++i) {
+            const pt_bvh_node& b = d->nodes[i];
+            if (!b.count) continue;
+            float4* h = &t[3 * size_t(slot_of[i])];
+            const uint32_t flags = (i == 0) ? kLeafUntested : 0u;
+            float ffl;
+            std::memcpy(&ffl, &flags, 4);
+            const pt_bvh_node& pb = d->nodes[parent[i]];
+            h[0] = make_float4(pb.lo[0], pb.lo[1], pb.lo[2], pb.hi[0]);
+            h[1] = make_float4(pb.hi[1], pb.hi[2], ffl, 0.0f);
+            h[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (uint32_t k = 0; k < b.count; ++k) {
+                const uint32_t prim = d->prim_ids[b.first + k];
+                const float* p0 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 0] - 1);
+                const float* p1 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 1] - 1);
+                const float* p2 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 2] - 1);
+                float fp;
+                std::memcpy(&fp, &prim, 4);
+                float4* o = h + 3 * size_t(1u + k);
+                o[0] = make_float4(p0[0], p0[1], p0[2], fp);
+                o[1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.0f);
+                o[2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f);
+            }
         }
         if (int rc = upload(s, t.data(), t.size(), &dev.tris)) return rc;
     }
@@ -273,7 +299,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             if (d->nodes[i].count == 0) wide_id[i] = n_wide++;
         auto ref_of = [&](uint32_t ni) -> uint32_t {
             const pt_bvh_node& b = d->nodes[ni];
-            return b.count ? (kLeafBit | (b.count << kLeafCountShift) | b.first) : wide_id[ni];
+            return b.count ? (kLeafBit | (b.count << kLeafCountShift) | slot_of[ni]) : wide_id[ni];
         };
         std::vector<float4> w(4 * size_t(std::max(n_wide, 1u)));
         for (uint32_t i = 0; i < d->n_nodes; ++i) {

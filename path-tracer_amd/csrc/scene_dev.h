@@ -5,7 +5,8 @@
 
 namespace ptd {
 
-// Leaf reference in the 2-wide layout: bit 31 set, triangle count in bits 27..30, first leaf slot in bits 0..26.
+// Leaf reference in the 2-wide layout: bit 31 set, triangle count in bits 27..30, the leaf's header slot in the leaf array
+// in bits 0..26 (its triangles follow in the next `count` slots).
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLeafCountShift = 27;
 constexpr uint32_t kLeafFirstMask = (1u << kLeafCountShift) - 1u;
@@ -47,7 +48,9 @@ struct DevScene {
     //      {c0.lo.xyz, c0.hi.x} {c0.hi.yz, c1.lo.xy} {c1.lo.z, c1.hi.xyz} {bits(ref0), bits(ref1), 0, 0}
     const float4* wide;
     uint32_t wide_root;  // reference of the root (an interior index, or a leaf reference for tiny scenes)
-    // ---- triangles in leaf order, 3 x float4 each: {p0.xyz, bits(prim)} {e1.xyz, 0} {e2.xyz, 0}
+    // ---- leaf array, 3 x float4 per slot: per leaf one header slot {P.lo.xyz, P.hi.x} {P.hi.yz, bits(flags), 0} {0}
+    //      (P = the leaf's parent node) followed by its triangles {p0.xyz, bits(prim)} {e1.xyz, 0} {e2.xyz, 0};
+    //      a binary leaf node's `first` is the slot of its first triangle
     const float4* tris;
     // ---- shading records (original triangle order) and light records (reference light order)
     const float4* trec;

@@ -232,6 +232,84 @@ PTD bool tri_hit(V3 p0, V3 e1, V3 e2, const V3& o, const V3& d, float min_dis, f
     return t >= min_dis && t <= max_dis;
 }
 
+// ------------------------------------------------------------------------------------------------ conservative slab test
+//
+// Why the ordered wave traversal may walk the tree with a cheap, padded slab test and still report what the reference
+// reports: AABB::intersect (src/aabb.cpp:6-35) is MONOTONE under box nesting.  For a ray with finite quotients and boxes
+// D inside A (the builder's boxes are exact unions, so lo_A <= lo_D <= hi_D <= hi_A holds exactly), every step that
+// leads to a quotient -- the subtraction, the correctly rounded division -- is monotone in the plane coordinate, hence
+// entry_A <= entry_D and exit_D <= exit_A per axis, in the reference's own arithmetic and without any error term.  The
+// reference accepts a box iff  max3(entries) <= min3(exits)  and  max(x, y entries) < max_dis  and
+// min(x, y exits) > min_dis  (its two early-outs and the final comparison are exactly that), so
+//      accept(D, bound)  implies  accept(A, bound)  for every ancestor A of D.
+// The reference reaches a leaf iff it accepts all interior ancestors, i.e. iff it accepts the leaf's PARENT box (leaves
+// are never box-tested, src/bvh.cpp:38-48).  So only one exact decision per visited leaf is needed: the leaf array holds
+// the parent's box in a header record in front of the leaf's triangles, and the lane evaluates box_decide() on it before
+// it tries the triangles.  Everything above the leaf is navigation, for which any test that never skips a box the
+// reference accepts (and that can hold an acceptable triangle) will do.
+//
+// box_cheap: entry / exit estimates from one fused multiply-add per plane, t = plane * (1/d) - o * (1/d).  Against the
+// reference's quotient the estimate is off by at most 2^-22 |t| (rounding of the difference, of 1/d and of the result)
+// plus 2^-24 |o / d| (rounding of the product o * (1/d)).  The second term is an absolute error on the scale of THAT
+// axis (huge for an axis the ray is nearly parallel to, where the slab is just as wide), so it is folded into the
+// addends per axis: the plane the ray meets first gets -o/d - pad, the other one -o/d + pad, pad = 2^-22 |o / d| -- the
+// slab only ever widens.  The relative term is covered by kCheapRel in cheap_go.
+constexpr float kCheapRel = 0x1p-19f;
+constexpr float kCheapPad = 0x1p-22f;
+
+// per-ray constants of box_cheap
+struct CheapRay {
+    V3 y;      // 1 / d
+    V3 a_lo;   // addend of the lo planes
+    V3 a_hi;   // addend of the hi planes
+    PTD void set(const RayPre& p) {
+        y = p.y;
+        const V3 noy{-(p.o.x * p.y.x), -(p.o.y * p.y.y), -(p.o.z * p.y.z)};
+        // d > 0: the lo plane is met first; d < 0: the hi plane
+        const V3 e{copysignf(kCheapPad * fabsf(noy.x), p.d.x), copysignf(kCheapPad * fabsf(noy.y), p.d.y), copysignf(kCheapPad * fabsf(noy.z), p.d.z)};
+        a_lo = V3{noy.x - e.x, noy.y - e.y, noy.z - e.z};
+        a_hi = V3{noy.x + e.x, noy.y + e.y, noy.z + e.z};
+    }
+};
+
+struct BoxC {
+    float tn, tf;  // entry and exit distance over all three (widened) slabs
+};
+
+PTD BoxC box_cheap(float lox, float loy, float loz, float hix, float hiy, float hiz, const CheapRay& r) {
+    const float x0 = __fmaf_rn(lox, r.y.x, r.a_lo.x), x1 = __fmaf_rn(hix, r.y.x, r.a_hi.x);
+    const float y0 = __fmaf_rn(loy, r.y.y, r.a_lo.y), y1 = __fmaf_rn(hiy, r.y.y, r.a_hi.y);
+    const float z0 = __fmaf_rn(loz, r.y.z, r.a_lo.z), z1 = __fmaf_rn(hiz, r.y.z, r.a_hi.z);
+    BoxC b;
+    b.tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    b.tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    return b;
+}
+
+// Can the subtree of a box with estimates b hold a triangle that is accepted in [tmin, far]?  `far` is the far bound
+// already widened by the caller (near-tie window).  Three conditions: the (widened) slabs overlap; the ray enters the box
+// before the far bound; it leaves the box after its near end -- with the same kNearTie margin on the scale of the entry
+// distance that box_reaches_range uses for boxes that end behind the origin.
+PTD bool cheap_go(const BoxC& b, float tmin, float far) {
+    const float tfp = __fmaf_rn(fabsf(b.tf), kCheapRel, b.tf);
+    return b.tn <= tfp && b.tn <= far && __fmaf_rn(1.0f / 8192.0f, fabsf(b.tn), tfp) >= tmin;
+}
+
+// Header record of a leaf in the triangle array: {P.lo.xyz, P.hi.x} {P.hi.yz, bits(flags), 0} {unused}, P = the leaf's
+// parent node.  kLeafUntested: the leaf is the root (the reference tests no box at all).
+constexpr uint32_t kLeafUntested = 1u;
+
+// The reference's decision on the parent box of the leaf at `slot`, with the ray's own far end as the bound (the bound
+// the reference holds when it pops the parent is never larger).  entry = the x/y entry distance it compared.
+PTD bool leaf_parent_accepts(const DevScene& sc, uint32_t slot, const RayPre& pre, float tmax, float& entry) {
+    const float4 h0 = sc.tris[3 * size_t(slot)], h1 = sc.tris[3 * size_t(slot) + 1];
+    entry = -__builtin_huge_valf();
+    if (as_u(h1.z) & kLeafUntested) return true;
+    const BoxT b = box_decide<false>(h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, pre);
+    entry = b.tn;
+    return b.overlap && b.tn < tmax;
+}
+
 PTD void load_tri(const DevScene& sc, uint32_t slot, V3& p0, V3& e1, V3& e2, int32_t& prim) {
     const float4 a = sc.tris[3 * size_t(slot) + 0];
     const float4 b = sc.tris[3 * size_t(slot) + 1];
@@ -396,7 +474,7 @@ PTD bool closest_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pr
             for (uint32_t k = 0; k < count; ++k) {
                 V3 p0, e1, e2;
                 int32_t prim;
-                load_tri(sc, first + k, p0, e1, e2, prim);
+                load_tri(sc, first + 1u + k, p0, e1, e2, prim);  // slot `first` is the leaf's header record
                 wc.tri();
                 float t, u, v;
                 if (tri_hit(p0, e1, e2, ray.o, ray.d, ray.tmin, window, t, u, v)) {
@@ -490,7 +568,7 @@ PTD bool any_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, u
             for (uint32_t k = 0; k < count; ++k) {
                 V3 p0, e1, e2;
                 int32_t prim;
-                load_tri(sc, first + k, p0, e1, e2, prim);
+                load_tri(sc, first + 1u + k, p0, e1, e2, prim);
                 wc.tri();
                 float t, u, v;
                 if (tri_hit(p0, e1, e2, ray.o, ray.d, ray.tmin, ray.tmax, t, u, v)) return true;

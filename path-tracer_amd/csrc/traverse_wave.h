@@ -3,12 +3,13 @@
 //   - box steps and triangle steps run in separate phases (all lanes of a phase execute the same code), and
 //   - lanes whose query has ended take the next ray from the queue as soon as too few lanes are left busy, instead of
 //     idling until the slowest lane of the wave is done.
-// The per-node work is that of closest_ordered_t / any_ordered_t (traverse.h): same box decisions, same near-tie
-// detection, and the same accepted triangles -- the wave form leaves out a little more that cannot hold one: leaves
-// whose box the ray misses (leaf_worth_a_visit) and, for closest hits, deferred subtrees that have fallen behind the best
-// hit by the time they are popped (DistStack).  Rays that need the plain-division slab test ("special") and queries
-// whose result could depend on the visit order are not handled here; they are handed back to the caller (`defer`),
-// which runs them through closest_fast / closest_exact_t / any_fast in a follow-up kernel.
+// The ordered lanes (ClosestLane, AnyLane) navigate with the conservative slab test box_cheap and take the reference's
+// exact box decision once per visited leaf, on the leaf's parent box (why that is enough: traverse.h, above box_cheap);
+// near-tie detection and the accepted triangles are those of closest_ordered_t / any_ordered_t.  Deferred subtrees that
+// have fallen behind the best hit by the time they are popped are dropped without a fetch (DistStack).  Rays that need
+// the plain-division slab test ("special") and queries whose result could depend on the visit order are not handled
+// here; they are handed back to the caller (`defer`), which runs them through closest_fast / closest_exact_t / any_fast
+// in a follow-up kernel.
 #pragma once
 
 #include "traverse.h"
@@ -25,6 +26,10 @@ constexpr uint32_t kDone = kLeafBit;     // a leaf reference without triangles: 
 #endif
 constexpr uint32_t kRefillBelow = PT_REFILL_BELOW;   // fetch new rays once fewer lanes than this are busy
 constexpr uint32_t kMinBoxLanes = PT_MIN_BOX_LANES;  // leave the box phase for the triangle phase once fewer lanes than this have a box step to do
+
+// Deferred-ray marker "trace this ray with the plain reference-order routine" (otherwise a deferred ray carries a distance
+// bound >= 0, or +inf for the generic ordered query).
+constexpr float kDeferExact = -1.0f;
 
 PTD uint32_t lane_id() { return __lane_id(); }
 
@@ -60,17 +65,21 @@ struct ClosestLane {
     PTD bool leaf_ready() const { return cur > kDone; }
     PTD bool finished() const { return cur == kDone; }
     RayPre pre;
+    CheapRay cr;
     float tmax;
     float best, window;
     bool near_tie;
+    bool replay;       // the winner's parent box is entered beyond the window behind the winner: only the full reference-order query is safe
     HitD hit;
     uint32_t cur;
 
     PTD void begin(const DevScene& sc, const RayD& ray, const RayPre& p) {
         pre = p;
+        cr.set(p);
         tmax = ray.tmax;
         best = window = ray.tmax;
         near_tie = false;
+        replay = false;
         hit = HitD{-1, 0.0f, 0.0f, 0.0f};
         cur = sc.wide_root;
     }
@@ -88,23 +97,22 @@ struct ClosestLane {
         }
     }
 
-    // one 2-wide node: both boxes are evaluated without branching
+    // one 2-wide node: both child boxes through the conservative test, leaf children like interior ones; leaves first
+    // (they can only tighten the bound), otherwise the nearer child
     template <class C>
     PTD void inner(const DevScene& sc, DistStack& st, C& wc) {
         const float4* w = sc.wide + 4 * size_t(cur);
         wc.node();
         const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
         const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
-        const BoxT b0 = box_decide<false>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
-        const BoxT b1 = box_decide<false>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
-        const bool l0 = (r0 & kLeafBit) != 0u, l1 = (r1 & kLeafBit) != 0u;
-        const bool go0 = l0 ? leaf_worth_a_visit(b0, pre.tmin, window) : (b0.overlap && b0.order <= window && box_reaches_range(b0, pre.tmin));
-        const bool go1 = l1 ? leaf_worth_a_visit(b1, pre.tmin, window) : (b1.overlap && b1.order <= window && box_reaches_range(b1, pre.tmin));
-        const float o0 = l0 ? -__builtin_huge_valf() : b0.order, o1 = l1 ? -__builtin_huge_valf() : b1.order;
+        const BoxC b0 = box_cheap(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, cr);
+        const BoxC b1 = box_cheap(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, cr);
+        const bool go0 = cheap_go(b0, pre.tmin, window), go1 = cheap_go(b1, pre.tmin, window);
+        const float o0 = (r0 & kLeafBit) ? -__builtin_huge_valf() : b0.tn, o1 = (r1 & kLeafBit) ? -__builtin_huge_valf() : b1.tn;
         if (go0 && go1) {
             const bool swap = o1 < o0;
             cur = swap ? r1 : r0;
-            st.push(swap ? r0 : r1, swap ? b0.order : b1.order);
+            st.push(swap ? r0 : r1, swap ? b0.tn : b1.tn);
         } else if (go0 || go1) {
             cur = go0 ? r0 : r1;
         } else {
@@ -112,32 +120,42 @@ struct ClosestLane {
         }
     }
 
+    // a leaf: first the reference's own decision on the parent box (see box_cheap in traverse.h), then its triangles
     template <class C>
     PTD void leaf(const DevScene& sc, DistStack& st, C& wc) {
         const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
-        for (uint32_t k = 0; k < count; ++k) {
-            V3 p0, e1, e2;
-            int32_t prim;
-            load_tri(sc, first + k, p0, e1, e2, prim);
-            wc.tri();
-            float t, u, v;
-            if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, window, t, u, v)) {
-                near_tie = !(hit.prim < 0 || t * (1.0f + kNearTie) < best);
-                if (hit.prim < 0 || t <= best) {
-                    best = t;
-                    hit.prim = prim;
-                    hit.t = t;
-                    hit.u = u;
-                    hit.v = v;
-                    window = fminf(best * (1.0f + kNearTie), tmax);
+        wc.tri();
+        float entry;
+        if (leaf_parent_accepts(sc, first, pre, tmax, entry)) {
+            for (uint32_t k = 0; k < count; ++k) {
+                V3 p0, e1, e2;
+                int32_t prim;
+                load_tri(sc, first + 1u + k, p0, e1, e2, prim);
+                wc.tri();
+                float t, u, v;
+                if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, window, t, u, v)) {
+                    near_tie = !(hit.prim < 0 || t * (1.0f + kNearTie) < best);
+                    if (hit.prim < 0 || t <= best) {
+                        best = t;
+                        hit.prim = prim;
+                        hit.t = t;
+                        hit.u = u;
+                        hit.v = v;
+                        // every bound the reference compares with an ancestor of this leaf is another candidate's distance
+                        // or the ray's far end, all beyond the window behind t (else near_tie / redo()); the ancestors'
+                        // entry distances are at most the parent's, so a parent entered within the window makes sure that
+                        // none of them is culled by such a bound
+                        replay = !(entry <= best * (1.0f + kNearTie));
+                        window = fminf(best * (1.0f + kNearTie), tmax);
+                    }
                 }
             }
         }
         next(st);
     }
 
-    PTD bool redo() const { return near_tie || (hit.prim >= 0 && tmax < __builtin_huge_valf() && !(best * (1.0f + kNearTie) < tmax)); }
-    PTD float redo_bound() const { return hit.t * (1.0f + 2.0f * kNearTie); }
+    PTD bool redo() const { return near_tie || replay || (hit.prim >= 0 && tmax < __builtin_huge_valf() && !(best * (1.0f + kNearTie) < tmax)); }
+    PTD float redo_bound() const { return (replay && hit.prim >= 0) ? kDeferExact : hit.t * (1.0f + 2.0f * kNearTie); }
 };
 
 struct AnyLane {
@@ -152,13 +170,15 @@ struct AnyLane {
     PTD bool leaf_ready() const { return cur > kDone; }
     PTD bool finished() const { return cur == kDone; }
     RayPre pre;
+    CheapRay cr;
     float tmax;
-    float far_end;  // tmax widened by the near-tie window: a box the ray enters (all three slabs) beyond it is skipped
+    float far_end;  // tmax widened by the near-tie window: a box the ray enters beyond it is skipped
     bool occluded;
     uint32_t cur;
 
     PTD void begin(const DevScene& sc, const RayD& ray, const RayPre& p) {
         pre = p;
+        cr.set(p);
         tmax = ray.tmax;
         far_end = ray.tmax * (1.0f + kNearTie);
         occluded = false;
@@ -166,19 +186,22 @@ struct AnyLane {
     }
     PTD void next(Stack& st) { cur = st.empty() ? kDone : st.pop(); }
 
+    // The reference's bound is constant for this query, so the leaves it reaches do not depend on the visit order: it
+    // reaches a leaf iff it accepts the leaf's parent box.  Any walk that visits every such leaf that can hold an accepted
+    // triangle, and tries a leaf's triangles only after the parent's exact test, returns what the reference returns.
     template <class C>
     PTD void inner(const DevScene& sc, Stack& st, C& wc) {
         const float4* w = sc.wide + 4 * size_t(cur);
         wc.node();
         const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
         const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
-        const BoxT b0 = box_decide<false>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
-        const BoxT b1 = box_decide<false>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
-        const bool l0 = (r0 & kLeafBit) != 0u, l1 = (r1 & kLeafBit) != 0u;
-        const bool go0 = l0 ? leaf_worth_a_visit(b0, pre.tmin, far_end) : (b0.overlap && b0.tn < tmax && b0.order <= far_end && box_reaches_range(b0, pre.tmin));
-        const bool go1 = l1 ? leaf_worth_a_visit(b1, pre.tmin, far_end) : (b1.overlap && b1.tn < tmax && b1.order <= far_end && box_reaches_range(b1, pre.tmin));
+        const BoxC b0 = box_cheap(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, cr);
+        const BoxC b1 = box_cheap(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, cr);
+        const bool go0 = cheap_go(b0, pre.tmin, far_end), go1 = cheap_go(b1, pre.tmin, far_end);
         if (go0 && go1) {
-            const bool swap = l1 && !l0;
+            // a leaf first (cheap, may end the query); otherwise the first-listed child, which the builder made the larger
+            // one for exactly this purpose (src/bvh.cpp:137-144)
+            const bool swap = (r1 & kLeafBit) && !(r0 & kLeafBit);
             cur = swap ? r1 : r0;
             st.push(swap ? r0 : r1);
         } else if (go0 || go1) {
@@ -191,16 +214,20 @@ struct AnyLane {
     template <class C>
     PTD void leaf(const DevScene& sc, Stack& st, C& wc) {
         const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
-        for (uint32_t k = 0; k < count; ++k) {
-            V3 p0, e1, e2;
-            int32_t prim;
-            load_tri(sc, first + k, p0, e1, e2, prim);
-            wc.tri();
-            float t, u, v;
-            if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, tmax, t, u, v)) {
-                occluded = true;
-                cur = kDone;
-                return;
+        wc.tri();
+        float entry;
+        if (leaf_parent_accepts(sc, first, pre, tmax, entry)) {
+            for (uint32_t k = 0; k < count; ++k) {
+                V3 p0, e1, e2;
+                int32_t prim;
+                load_tri(sc, first + 1u + k, p0, e1, e2, prim);
+                wc.tri();
+                float t, u, v;
+                if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, tmax, t, u, v)) {
+                    occluded = true;
+                    cur = kDone;
+                    return;
+                }
             }
         }
         next(st);
@@ -347,9 +374,6 @@ struct ExactAnyLane {
     }
 };
 
-// Deferred-ray marker of the reference-order kernels (the ordered ones put a distance bound >= 0 or +inf there): the
-// follow-up pass traces the ray with the plain reference-order routine.
-constexpr float kDeferExact = -1.0f;
 
 // lane states of the shared loop
 constexpr int kLaneEmpty = 0, kLaneBusy = 1, kLaneDone = 2;
