@@ -126,13 +126,14 @@ struct PassArgs {
 // word 4 + 4k holds the node records fetched and the u64 at word 6 + 4k the triangle records fetched.
 constexpr int kMiscWords = 16;
 
+// A ray that a wave-refill kernel handed back, in reference order: the whole query (plain-division rays, kDeferExact), or
+// bounded by `bound` when the ordered pass has already established that the nearest accepted triangle lies before it.
 template <class C>
-PTD bool trace_closest(const DevScene& sc, int traversal, const RayD& ray, HitD& hit, uint32_t* lds, uint32_t* retrace_counter, C& wc) {
-    if (traversal == 0) return closest_exact(sc, ray, hit, lds, wc);
-    bool redo;  // two candidates too close for the visit order not to matter: closest_fast has repeated the query
-    const bool found = closest_fast(sc, ray, hit, redo, lds, wc);
-    if (redo && retrace_counter) atomicAdd(retrace_counter, 1u);
-    return found;
+PTD bool trace_deferred(const DevScene& sc, const RayD& ray, float bound, HitD& hit, uint32_t* lds, uint32_t* retrace_counter, C& wc) {
+    const RayPre pre = make_pre(sc, ray);
+    if (bound == kDeferExact || pre.special) return closest_exact(sc, ray, hit, lds, wc);
+    if (retrace_counter) atomicAdd(retrace_counter, 1u);
+    return closest_exact_t<false>(sc, ray, pre, bound, hit, lds, wc);
 }
 
 // add a wave's work counters to the global 64-bit totals (counting builds only)
@@ -154,9 +155,9 @@ PTD void flush_counts(const Count& c, uint32_t* misc, int kernel_class) {
 
 // ------------------------------------------------------------------------------------------------ batched queries
 
+// one lane per ray, reference order
 template <class C>
-__global__ __launch_bounds__(kBlock) void k_intersect(DevScene sc, const float4* rays, uint32_t n, float4* hits, int mode,
-                                                       uint32_t* misc) {
+__global__ __launch_bounds__(kBlock) void k_intersect(DevScene sc, const float4* rays, uint32_t n, float4* hits, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     C wc;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene sc, const float4*
         const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
         const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
         HitD h;
-        trace_closest(sc, mode, ray, h, s_stack + threadIdx.x, misc, wc);
+        closest_exact(sc, ray, h, s_stack + threadIdx.x, wc);
         hits[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
     }
     flush_counts(wc, misc, 1);
@@ -172,19 +173,15 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene sc, const float4*
 
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_occluded(DevScene sc, const float4* rays, uint32_t n, uint8_t* occ, int32_t* first_prim,
-                                                      int mode, uint32_t* misc) {
+                                                      uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     C wc;
     if (i < n) {
         const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
         const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
-        bool hit;
-        int32_t fp = -2;
-        if (mode == 0)
-            hit = any_exact(sc, ray, fp, s_stack + threadIdx.x, wc);
-        else
-            hit = any_fast(sc, ray, s_stack + threadIdx.x, wc);
+        int32_t fp = -1;
+        const bool hit = any_exact(sc, ray, fp, s_stack + threadIdx.x, wc);
         occ[i] = hit ? 1 : 0;
         if (first_prim) first_prim[i] = hit ? fp : -1;
     }
@@ -197,6 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded(DevScene sc, const float4* 
 // then the camera ray and the first Scene::rayIntersect of PathIntegrator::Li (src/integrator.cpp:46-53).
 // For the two AOV integrators (src/integrator.cpp:20-43) the result is final and goes straight to lbuf.
 // Paths that hit something enter path queue `q` and hit list `hq` at the same position of their slot's shard.
+// One lane per sample slot, reference order (the ordered mode uses k_generate_wave).
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, PathQ q, HitQ hq, float4* lbuf, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];
@@ -230,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
             pa.list_pixel_sample[2 * size_t(slot) + 1] = ps.y;
         }
         camera_ray(sc.cam, ps, ray.o, ray.d, ray.tmin, ray.tmax);
-        alive = trace_closest(sc, pa.traversal, ray, h, s_stack + threadIdx.x, misc, wc);
+        alive = closest_exact(sc, ray, h, s_stack + threadIdx.x, wc);
         V3 out = mk3(0.0f);
         if (alive && pa.integrator != 0) {
             TriRec t;
@@ -371,17 +369,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE
                 j = load_fresh(&io.dq.e[sbase + k].x);
                 const float bound = as_f(load_fresh(&io.dq.e[sbase + k].y));
                 io.load(sc, shard, j, ray, c);
-                bool redo = true;
-                if (bound == kDeferExact) {
-                    closest_exact(sc, ray, h, s_stack + threadIdx.x, wc);
-                    redo = false;
-                } else if (bound == __builtin_huge_valf()) {
-                    closest_fast(sc, ray, h, redo, s_stack + threadIdx.x, wc);
-                } else {
-                    const RayPre pre = make_pre(sc, ray);
-                    closest_exact_t<false>(sc, ray, pre, bound, h, s_stack + threadIdx.x, wc);
-                }
-                if (redo && misc) atomicAdd(misc, 1u);
+                trace_deferred(sc, ray, bound, h, s_stack + threadIdx.x, misc, wc);
             }
             io.emit(sc, shard, k < n, j, h, c, ray.o, ray.d);
         }
@@ -430,8 +418,7 @@ struct ExtendIo {
     }
 };
 
-// The deferred rays of one shard, by one workgroup: special rays through the generic ordered query, order-sensitive ones
-// in reference order up to their bound.
+// The deferred rays of one shard, by one workgroup, in reference order (order-sensitive ones only up to their bound).
 template <class C>
 PTD void extend_deferred(const DevScene& sc, const PathQ& q, const HitQ& hq, const DeferQ& dq, uint32_t shard, uint32_t* lds_stack,
                          uint32_t* misc, C& wc) {
@@ -449,17 +436,7 @@ PTD void extend_deferred(const DevScene& sc, const PathQ& q, const HitQ& hq, con
             const float4 a = q.a[sbase + j], b = q.b[sbase + j];
             c = q.c[sbase + j];
             const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
-            bool redo = true;
-            if (bound == kDeferExact) {
-                found = closest_exact(sc, ray, h, lds_stack, wc);
-                redo = false;
-            } else if (bound == __builtin_huge_valf()) {
-                found = closest_fast(sc, ray, h, redo, lds_stack, wc);
-            } else {
-                const RayPre pre = make_pre(sc, ray);
-                found = closest_exact_t<false>(sc, ray, pre, bound, h, lds_stack, wc);
-            }
-            if (redo && misc) atomicAdd(misc, 1u);
+            found = trace_deferred(sc, ray, bound, h, lds_stack, misc, wc);
         }
         const uint32_t local = wave_alloc(found, hq.count + shard);
         if (found) {
@@ -532,7 +509,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE
             const float4 a = io.sh.a[sbase + j], b = io.sh.b[sbase + j];
             const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
             int32_t first_prim;
-            if (!(Lane::kReferenceOrder ? any_exact(sc, ray, first_prim, s_stack + threadIdx.x, wc) : any_fast(sc, ray, s_stack + threadIdx.x, wc))) {
+            if (!any_exact(sc, ray, first_prim, s_stack + threadIdx.x, wc)) {
                 const float4 v = io.sh.c[sbase + j];
                 const uint32_t slot = as_u(b.w);
                 float4 L = io.lbuf[slot];
@@ -588,16 +565,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_fix(DevScene sc, const flo
             const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
             const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
             HitD h;
-            bool redo = true;
-            if (m.y == kDeferExact) {
-                closest_exact(sc, ray, h, s_stack + threadIdx.x, wc);
-            } else if (m.y == __builtin_huge_valf()) {
-                closest_fast(sc, ray, h, redo, s_stack + threadIdx.x, wc);
-            } else {
-                const RayPre pre = make_pre(sc, ray);
-                closest_exact_t<false>(sc, ray, pre, m.y, h, s_stack + threadIdx.x, wc);
-            }
-            if (redo && misc) atomicAdd(misc, 1u);
+            trace_deferred(sc, ray, m.y, h, s_stack + threadIdx.x, misc, wc);
             hits[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
         }
     }
@@ -640,7 +608,8 @@ __global__ __launch_bounds__(kBlock) void k_occluded_fix(DevScene sc, const floa
         if (o == 2) {
             const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
             const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
-            o = any_fast(sc, ray, s_stack + threadIdx.x, wc) ? 1 : 0;
+            int32_t fp;
+            o = any_exact(sc, ray, fp, s_stack + threadIdx.x, wc) ? 1 : 0;
             occ[i] = o;
         }
         if (first_prim) first_prim[i] = o ? -2 : -1;

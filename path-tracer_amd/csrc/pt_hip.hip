@@ -228,7 +228,9 @@ int validate(const pt_scene_desc* d, uint32_t& depth_out) {
         }
     }
     if (leaf_prims != d->n_tris) return fail(PT_ERR_INVALID, "BVH leaves do not cover every triangle exactly once");
-    if (depth + 2 > uint32_t(kMaxStack)) return fail(PT_ERR_LIMIT, "BVH deeper than the traversal stack (" + std::to_string(kMaxStack - 2) + ")");
+    // reference order: one deferred sibling per level; ordered mode: up to three deferred slots per two levels
+    if (depth + 2 > uint32_t(kMaxStack) || 3 * ((depth + 1) / 2) + 4 > uint32_t(kMaxStack))
+        return fail(PT_ERR_LIMIT, "BVH deeper than the traversal stack (" + std::to_string(2 * ((kMaxStack - 4) / 3)) + " levels)");
     depth_out = depth;
     return PT_OK;
 }
@@ -291,34 +293,81 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
         }
         if (int rc = upload(s, t.data(), t.size(), &dev.tris)) return rc;
     }
-    // ordered 2-wide nodes: one record per interior node, numbered in binary-node order
+    // navigation nodes of the ordered traversal: 4-wide, 64 bytes each, slot boxes on a 16-bit grid over the root box,
+    // rounded outwards (box_cheap in traverse.h)
     {
-        std::vector<uint32_t> wide_id(d->n_nodes, 0);
-        uint32_t n_wide = 0;
-        for (uint32_t i = 0; i < d->n_nodes; ++i)
-            if (d->nodes[i].count == 0) wide_id[i] = n_wide++;
+        const pt_bvh_node& root = d->nodes[0];
+        double org[3], step[3];
+        for (int a = 0; a < 3; ++a) {
+            dev.q_org[a] = root.lo[a];
+            // spacing rounded up so that grid point 65535 lies at or beyond the far face; never zero (flat scenes)
+            const float st = float(std::max((double(root.hi[a]) - double(root.lo[a])) / 65535.0 * (1.0 + 1e-6), 1e-30));
+            dev.q_step[a] = st;
+            org[a] = dev.q_org[a];
+            step[a] = dev.q_step[a];
+        }
+        auto q_lo = [&](float v, int a) -> uint32_t {  // largest grid point at or below v, minus one step of safety
+            const double g = std::floor((double(v) - org[a]) / step[a]) - 1.0;
+            return uint32_t(std::min(65535.0, std::max(0.0, g)));
+        };
+        auto q_hi = [&](float v, int a) -> uint32_t {  // smallest grid point at or above v, plus one step of safety
+            const double g = std::ceil((double(v) - org[a]) / step[a]) + 1.0;
+            return uint32_t(std::min(65535.0, std::max(0.0, g)));
+        };
+        // Collapse: the navigation node of binary interior node N has one slot per grandchild of N, or per child where
+        // that child is a leaf.  Nodes are numbered in depth-first order from the root (a subtree is contiguous).
+        std::vector<uint32_t> wide_id(d->n_nodes, kEmptyRef), order;
+        {
+            std::vector<uint32_t> stack;
+            if (d->nodes[0].count == 0) stack.push_back(0u);
+            while (!stack.empty()) {
+                const uint32_t n = stack.back();
+                stack.pop_back();
+                wide_id[n] = uint32_t(order.size());
+                order.push_back(n);
+                uint32_t slots[kWide];
+                int ns = 0;
+                for (uint32_t k = 0; k < 2; ++k) {
+                    const uint32_t c = d->nodes[n].first + k;
+                    if (d->nodes[c].count) {
+                        slots[ns++] = c;
+                    } else {
+                        slots[ns++] = d->nodes[c].first;
+                        slots[ns++] = d->nodes[c].first + 1;
+                    }
+                }
+                for (int k = ns - 1; k >= 0; --k)
+                    if (d->nodes[slots[k]].count == 0) stack.push_back(slots[k]);
+            }
+        }
         auto ref_of = [&](uint32_t ni) -> uint32_t {
             const pt_bvh_node& b = d->nodes[ni];
             return b.count ? (kLeafBit | (b.count << kLeafCountShift) | slot_of[ni]) : wide_id[ni];
         };
-        std::vector<float4> w(4 * size_t(std::max(n_wide, 1u)));
-        for (uint32_t i = 0; i < d->n_nodes; ++i) {
-            const pt_bvh_node& b = d->nodes[i];
-            if (b.count) continue;
-            const pt_bvh_node& c0 = d->nodes[b.first];
-            const pt_bvh_node& c1 = d->nodes[b.first + 1];
-            const uint32_t r0 = ref_of(b.first), r1 = ref_of(b.first + 1);
-            float f0, f1;
-            std::memcpy(&f0, &r0, 4);
-            std::memcpy(&f1, &r1, 4);
-            float4* o = &w[4 * size_t(wide_id[i])];
-            o[0] = make_float4(c0.lo[0], c0.lo[1], c0.lo[2], c0.hi[0]);
-            o[1] = make_float4(c0.hi[1], c0.hi[2], c1.lo[0], c1.lo[1]);
-            o[2] = make_float4(c1.lo[2], c1.hi[0], c1.hi[1], c1.hi[2]);
-            o[3] = make_float4(f0, f1, 0.0f, 0.0f);
+        std::vector<uint4> w(size_t(kWide) * std::max<size_t>(order.size(), 1), make_uint4(0u, 0u, 0u, kEmptyRef));
+        for (size_t wi = 0; wi < order.size(); ++wi) {
+            const uint32_t n = order[wi];
+            int ns = 0;
+            auto put = [&](uint32_t ci) {
+                const pt_bvh_node& c = d->nodes[ci];
+                uint4& o = w[size_t(kWide) * wi + ns++];
+                o.x = q_lo(c.lo[0], 0) | (q_hi(c.hi[0], 0) << 16);
+                o.y = q_lo(c.lo[1], 1) | (q_hi(c.hi[1], 1) << 16);
+                o.z = q_lo(c.lo[2], 2) | (q_hi(c.hi[2], 2) << 16);
+                o.w = ref_of(ci);
+            };
+            for (uint32_t k = 0; k < 2; ++k) {
+                const uint32_t c = d->nodes[n].first + k;
+                if (d->nodes[c].count) {
+                    put(c);
+                } else {
+                    put(d->nodes[c].first);
+                    put(d->nodes[c].first + 1);
+                }
+            }
         }
         dev.wide_root = ref_of(0);
-        if (int rc = upload(s, w.data(), w.size(), &dev.wide)) return rc;
+        if (int rc = upload(s, w.data(), w.size(), &dev.qnodes)) return rc;
     }
     // shading records: one 128-byte record per triangle, one 96-byte record per light
     {
@@ -761,7 +810,7 @@ int launch_intersect(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_hit* d_
                            hits, (uint32_t*)nullptr);
     } else {
         hipLaunchKernelGGL(k_intersect<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev, rays, uint32_t(n), hits,
-                           mode, (uint32_t*)nullptr);
+                           (uint32_t*)nullptr);
     }
     return PT_OK;
 }
@@ -781,7 +830,7 @@ int launch_occluded(pt_hip_scene* s, const pt_ray* d_rays, size_t n, uint8_t* d_
                            d_occ, d_first, (uint32_t*)nullptr);
     } else {
         hipLaunchKernelGGL(k_occluded<NoCount>, dim3(blocks(uint32_t(n), kBlock)), dim3(kBlock), 0, g_stream, s->dev, rays, uint32_t(n), d_occ,
-                           d_first, mode, (uint32_t*)nullptr);
+                           d_first, (uint32_t*)nullptr);
     }
     return PT_OK;
 }

@@ -5,7 +5,7 @@
 
 namespace ptd {
 
-// Leaf reference in the 2-wide layout: bit 31 set, triangle count in bits 27..30, the leaf's header slot in the leaf array
+// Leaf reference in the navigation nodes: bit 31 set, triangle count in bits 27..30, the leaf's header slot in the leaf array
 // in bits 0..26 (its triangles follow in the next `count` slots).
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLeafCountShift = 27;
@@ -44,9 +44,10 @@ struct DevScene {
     // ---- traversal, reference order: binary nodes, 2 x float4 each:
     //      {lo.x, lo.y, lo.z, hi.x} {hi.y, hi.z, bits(first), bits(count)}
     const float4* nodes;
-    // ---- traversal, ordered: one record per interior node, 4 x float4:
-    //      {c0.lo.xyz, c0.hi.x} {c0.hi.yz, c1.lo.xy} {c1.lo.z, c1.hi.xyz} {bits(ref0), bits(ref1), 0, 0}
-    const float4* wide;
+    // ---- traversal, ordered: 4-wide navigation nodes, 64 bytes = 4 x uint4 each (see box_cheap in traverse.h):
+    //      per slot {c.x, c.y, c.z, ref}, c.x = lo.x | hi.x << 16 on the grid q_org + q * q_step
+    const uint4* qnodes;
+    float q_org[3], q_step[3];
     uint32_t wide_root;  // reference of the root (an interior index, or a leaf reference for tiny scenes)
     // ---- leaf array, 3 x float4 per slot: per leaf one header slot {P.lo.xyz, P.hi.x} {P.hi.yz, bits(flags), 0} {0}
     //      (P = the leaf's parent node) followed by its triangles {p0.xyz, bits(prim)} {e1.xyz, 0} {e2.xyz, 0};

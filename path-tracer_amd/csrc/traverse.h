@@ -14,8 +14,10 @@
 //     once per ray, one multiply, two fused residual corrections); rays with a zero, tiny, huge or non-finite direction
 //     component are "special" and take the plain IEEE division so that the NaN / infinity cases come out as in the
 //     reference, and so does any box for which one of the quotient estimates is zero or tiny;
-//   - the ordered mode differs from the reference only in the ORDER in which accepted subtrees are visited and in
-//     culling by distance, and falls back to the reference order whenever order could matter (see closest_ordered_t).
+//   - the ordered mode (traverse_wave.h) navigates with a conservative test and takes this exact decision once per
+//     visited leaf, on the leaf's parent box (see box_cheap below for why that is enough); it differs from the reference
+//     only in the ORDER in which subtrees are visited and in culling by distance, and falls back to the reference order
+//     whenever order could matter.
 //
 // Per-lane traversal stack: the first kLdsDepth entries live in LDS, laid out [entry][lane] so that a wave's 64 lanes
 // hit 64 consecutive banks; deeper entries spill to a private (scratch) array.  The host rejects trees deeper than
@@ -248,27 +250,45 @@ PTD bool tri_hit(V3 p0, V3 e1, V3 e2, const V3& o, const V3& d, float min_dis, f
 // it tries the triangles.  Everything above the leaf is navigation, for which any test that never skips a box the
 // reference accepts (and that can hold an acceptable triangle) will do.
 //
-// box_cheap: entry / exit estimates from one fused multiply-add per plane, t = plane * (1/d) - o * (1/d).  Against the
-// reference's quotient the estimate is off by at most 2^-22 |t| (rounding of the difference, of 1/d and of the result)
-// plus 2^-24 |o / d| (rounding of the product o * (1/d)).  The second term is an absolute error on the scale of THAT
-// axis (huge for an axis the ray is nearly parallel to, where the slab is just as wide), so it is folded into the
-// addends per axis: the plane the ray meets first gets -o/d - pad, the other one -o/d + pad, pad = 2^-22 |o / d| -- the
-// slab only ever widens.  The relative term is covered by kCheapRel in cheap_go.
+// Navigation nodes (DevScene::qnodes): a 4-wide tree collapsed from the reference's binary tree (a node's slots are its
+// grandchildren, or a child itself where that child is a leaf), one 64-byte record per node: per slot the box as 16-bit
+// coordinates on a grid over the scene bounds (origin q_org, spacing q_step per axis), rounded outwards by at least one
+// grid step, and the reference of the slot's subtree:
+//      4 x {c.x, c.y, c.z, ref},   c.x = lo.x | hi.x << 16  etc.,  ref = kEmptyRef for an unused slot.
+// With the exact decisions gone from the interior nodes the traversal kernels are bound by the latency of the dependent
+// node fetches (a handful of waves per SIMD, each waiting for its next node), so the layout halves the number of
+// fetches on a ray's way down: 16 bytes per box instead of 24 + reference, two tree levels per fetch.
+//
+// box_cheap: entry / exit estimates t = ((q_org + q * q_step) - o) / d from one convert and one fused multiply-add per
+// plane, t = q * A + B with the per-ray constants A = q_step / d, B = (q_org - o) / d.  Against the exact value the
+// estimate is off by at most 2^-22 (|q_org - o| + extent) / |d| (roundings of 1/d, A, B and the difference) plus
+// 2^-24 |t|.  The first term is an absolute error on the scale of THAT axis (huge for an axis the ray is nearly
+// parallel to, where the slab is just as wide), so it is folded into B per axis: the plane the ray meets first gets
+// B - pad, the other one B + pad, pad = kCheapPad (|q_org - o| + extent) / |d| -- the slab only ever widens.  The
+// relative term, and the 2^-23 |t| by which the reference's own quotient differs from the exact one, are covered by
+// kCheapRel in cheap_go.
 constexpr float kCheapRel = 0x1p-19f;
-constexpr float kCheapPad = 0x1p-22f;
+constexpr float kCheapPad = 0x1p-21f;
+// Relative width of the distance window inside which two candidates count as "equally near" for the purpose of
+// deciding whether visit order can matter (ClosestLane in traverse_wave.h); also the margin by which box and triangle
+// distances of the same geometry are assumed to agree.
+constexpr float kNearTie = 1.0f / 8192.0f;
 
 // per-ray constants of box_cheap
 struct CheapRay {
-    V3 y;      // 1 / d
-    V3 a_lo;   // addend of the lo planes
-    V3 a_hi;   // addend of the hi planes
-    PTD void set(const RayPre& p) {
-        y = p.y;
-        const V3 noy{-(p.o.x * p.y.x), -(p.o.y * p.y.y), -(p.o.z * p.y.z)};
+    V3 a;      // q_step / d
+    V3 b_lo;   // addend of the lo planes
+    V3 b_hi;   // addend of the hi planes
+    PTD void set(const DevScene& sc, const RayPre& p) {
+        const V3 org{sc.q_org[0], sc.q_org[1], sc.q_org[2]}, step{sc.q_step[0], sc.q_step[1], sc.q_step[2]};
+        a = V3{step.x * p.y.x, step.y * p.y.y, step.z * p.y.z};
+        const V3 rel = org - p.o;
+        const V3 c{rel.x * p.y.x, rel.y * p.y.y, rel.z * p.y.z};
         // d > 0: the lo plane is met first; d < 0: the hi plane
-        const V3 e{copysignf(kCheapPad * fabsf(noy.x), p.d.x), copysignf(kCheapPad * fabsf(noy.y), p.d.y), copysignf(kCheapPad * fabsf(noy.z), p.d.z)};
-        a_lo = V3{noy.x - e.x, noy.y - e.y, noy.z - e.z};
-        a_hi = V3{noy.x + e.x, noy.y + e.y, noy.z + e.z};
+        const V3 e{copysignf(kCheapPad * (fabsf(c.x) + 65535.0f * fabsf(a.x)), p.d.x), copysignf(kCheapPad * (fabsf(c.y) + 65535.0f * fabsf(a.y)), p.d.y),
+                   copysignf(kCheapPad * (fabsf(c.z) + 65535.0f * fabsf(a.z)), p.d.z)};
+        b_lo = c - e;
+        b_hi = c + e;
     }
 };
 
@@ -276,10 +296,11 @@ struct BoxC {
     float tn, tf;  // entry and exit distance over all three (widened) slabs
 };
 
-PTD BoxC box_cheap(float lox, float loy, float loz, float hix, float hiy, float hiz, const CheapRay& r) {
-    const float x0 = __fmaf_rn(lox, r.y.x, r.a_lo.x), x1 = __fmaf_rn(hix, r.y.x, r.a_hi.x);
-    const float y0 = __fmaf_rn(loy, r.y.y, r.a_lo.y), y1 = __fmaf_rn(hiy, r.y.y, r.a_hi.y);
-    const float z0 = __fmaf_rn(loz, r.y.z, r.a_lo.z), z1 = __fmaf_rn(hiz, r.y.z, r.a_hi.z);
+// cx, cy, cz: the three plane words of one child (lo in the low half, hi in the high half)
+PTD BoxC box_cheap(uint32_t cx, uint32_t cy, uint32_t cz, const CheapRay& r) {
+    const float x0 = __fmaf_rn(float(cx & 0xffffu), r.a.x, r.b_lo.x), x1 = __fmaf_rn(float(cx >> 16), r.a.x, r.b_hi.x);
+    const float y0 = __fmaf_rn(float(cy & 0xffffu), r.a.y, r.b_lo.y), y1 = __fmaf_rn(float(cy >> 16), r.a.y, r.b_hi.y);
+    const float z0 = __fmaf_rn(float(cz & 0xffffu), r.a.z, r.b_lo.z), z1 = __fmaf_rn(float(cz >> 16), r.a.z, r.b_hi.z);
     BoxC b;
     b.tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
     b.tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
@@ -288,12 +309,16 @@ PTD BoxC box_cheap(float lox, float loy, float loz, float hix, float hiy, float 
 
 // Can the subtree of a box with estimates b hold a triangle that is accepted in [tmin, far]?  `far` is the far bound
 // already widened by the caller (near-tie window).  Three conditions: the (widened) slabs overlap; the ray enters the box
-// before the far bound; it leaves the box after its near end -- with the same kNearTie margin on the scale of the entry
-// distance that box_reaches_range uses for boxes that end behind the origin.
+// before the far bound; it leaves the box after its near end, with a margin of kNearTie on the scale of the entry
+// distance (for a box that ends behind the ray's origin the entry is the larger of its two distances, the scale of the
+// rounding errors of the triangle distances inside the box).
 PTD bool cheap_go(const BoxC& b, float tmin, float far) {
     const float tfp = __fmaf_rn(fabsf(b.tf), kCheapRel, b.tf);
-    return b.tn <= tfp && b.tn <= far && __fmaf_rn(1.0f / 8192.0f, fabsf(b.tn), tfp) >= tmin;
+    return b.tn <= tfp && b.tn <= far && __fmaf_rn(kNearTie, fabsf(b.tn), tfp) >= tmin;
 }
+
+constexpr uint32_t kEmptyRef = 0xffffffffu;  // unused slot of a navigation node
+constexpr int kWide = 4;                      // slots per navigation node
 
 // Header record of a leaf in the triangle array: {P.lo.xyz, P.hi.x} {P.hi.yz, bits(flags), 0} {unused}, P = the leaf's
 // parent node.  kLeafUntested: the leaf is the root (the reference tests no box at all).
@@ -303,11 +328,10 @@ constexpr uint32_t kLeafUntested = 1u;
 // the reference holds when it pops the parent is never larger).  entry = the x/y entry distance it compared.
 PTD bool leaf_parent_accepts(const DevScene& sc, uint32_t slot, const RayPre& pre, float tmax, float& entry) {
     const float4 h0 = sc.tris[3 * size_t(slot)], h1 = sc.tris[3 * size_t(slot) + 1];
-    entry = -__builtin_huge_valf();
-    if (as_u(h1.z) & kLeafUntested) return true;
     const BoxT b = box_decide<false>(h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, pre);
-    entry = b.tn;
-    return b.overlap && b.tn < tmax;
+    const bool untested = (as_u(h1.z) & kLeafUntested) != 0u;
+    entry = untested ? -__builtin_huge_valf() : b.tn;
+    return untested || (b.overlap && b.tn < tmax);
 }
 
 PTD void load_tri(const DevScene& sc, uint32_t slot, V3& p0, V3& e1, V3& e2, int32_t& prim) {
@@ -420,197 +444,6 @@ PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uin
     const RayPre pre = make_pre(sc, ray);
     if (pre.special) return any_exact_t<true>(sc, ray, pre, first_prim, lds_stack, wc);
     return any_exact_t<false>(sc, ray, pre, first_prim, lds_stack, wc);
-}
-
-// ------------------------------------------------------------------------------------------------ ordered, 2-wide
-
-// Relative width of the distance window inside which two candidates count as "equally near" for the purpose of
-// deciding whether visit order can matter (see closest_ordered_t).
-constexpr float kNearTie = 1.0f / 8192.0f;
-
-// A box that the ray has left (all three slabs) before its own near end holds no triangle that is accepted within the
-// ray's range; the reference still enters it when only the z slab lies behind the origin (its test looks at the x/y
-// exit alone).  Margin: kNearTie of the box's entry distance -- for a box that ends behind the ray's origin the entry is
-// the larger of its two distances, the scale of the rounding errors of the triangle distances inside the box.
-// Comparisons are false for NaN: callers use this for finite quotients only.
-PTD bool box_reaches_range(const BoxT& b, float tmin) { return __fmaf_rn(kNearTie, fabsf(b.order), b.leave) >= tmin; }
-
-// Leaf children are not box-tested by the reference (src/bvh.cpp:38-48): their triangles are simply tried.  A leaf whose
-// box the ray misses by more than the same margin (it enters, all three slabs, after it has left; or outside the
-// range [tmin, bound]) cannot have an accepted triangle, so the ordered traversal does not fetch it.
-PTD bool leaf_worth_a_visit(const BoxT& b, float tmin, float bound) {
-    const float leave = __fmaf_rn(kNearTie, fabsf(b.order), b.leave);
-    return b.order <= leave && leave >= tmin && b.order <= bound;
-}
-
-// Ordered closest hit on the 2-wide layout.
-//
-// Same candidate set as the reference: an interior child is entered only if the reference's slab test accepts its box
-// (box_decide, identical decisions), leaf children are never box-tested (src/bvh.cpp:38-48), triangles use the same
-// test.  Differences: the nearer child is visited first, a subtree is skipped when the distance at which the ray
-// enters its box (all three slabs) lies beyond the current best hit by more than the kNearTie window, and when the ray
-// has left its box before the near end of its range (box_reaches_range) -- neither subtree holds a candidate.
-//
-// When is the result the reference's?  Let G be the nearest accepted triangle among all leaves reachable through
-// accepted boxes.  If no other candidate (and not the ray's own far end) lies within the kNearTie window of t_G, then
-// in the reference every bound that is ever compared with the entry distance of one of G's ancestors is either the
-// ray's far end or the distance of some other candidate, i.e. larger than t_G by more than the window, so the
-// reference reaches and keeps G as well.  Otherwise `redo` is set and the caller repeats the query in reference order.
-template <bool SPECIAL, class C>
-PTD bool closest_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, HitD& hit, bool& redo, uint32_t* lds_stack, C& wc) {
-    uint32_t spill[kSpillDepth];
-    Stack st;
-    st.init(lds_stack, spill);
-    float best = ray.tmax;    // distance bound as the reference would hold it once the winner is found
-    float window = ray.tmax;  // candidates up to here are still looked at
-    bool near_tie = false;
-    hit.prim = -1;
-    hit.t = 0.0f;
-    hit.u = hit.v = 0.0f;
-    uint32_t cur = sc.wide_root;
-    for (;;) {
-        if (cur & kLeafBit) {
-            const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
-            for (uint32_t k = 0; k < count; ++k) {
-                V3 p0, e1, e2;
-                int32_t prim;
-                load_tri(sc, first + 1u + k, p0, e1, e2, prim);  // slot `first` is the leaf's header record
-                wc.tri();
-                float t, u, v;
-                if (tri_hit(p0, e1, e2, ray.o, ray.d, ray.tmin, window, t, u, v)) {
-                    // first candidate, or clearly nearer than everything seen so far: no competitor (yet);
-                    // otherwise it lies within the window of the current winner, before or behind it
-                    near_tie = !(hit.prim < 0 || t * (1.0f + kNearTie) < best);
-                    if (hit.prim < 0 || t <= best) {
-                        best = t;
-                        hit.prim = prim;
-                        hit.t = t;
-                        hit.u = u;
-                        hit.v = v;
-                        window = fminf(best * (1.0f + kNearTie), ray.tmax);
-                    }
-                }
-            }
-        } else {
-            const float4* w = sc.wide + 4 * size_t(cur);
-            wc.node();
-            const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-            const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
-            // leaf children are visited unconditionally, like the reference does; interior children by the slab test
-            bool go0 = true, go1 = true;
-            float o0 = -__builtin_huge_valf(), o1 = -__builtin_huge_valf();
-            if (!(r0 & kLeafBit)) {
-                const BoxT b = box_decide<SPECIAL>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
-                go0 = b.overlap && b.order <= window && (SPECIAL || box_reaches_range(b, ray.tmin));
-                o0 = b.order;
-            }
-            if (!(r1 & kLeafBit)) {
-                const BoxT b = box_decide<SPECIAL>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
-                go1 = b.overlap && b.order <= window && (SPECIAL || box_reaches_range(b, ray.tmin));
-                o1 = b.order;
-            }
-            if (go0 && go1) {
-                const bool swap = o1 < o0;  // leaves (order -inf) first: they can only tighten the bound
-                cur = swap ? r1 : r0;
-                st.push(swap ? r0 : r1);
-                continue;
-            }
-            if (go0 || go1) {
-                cur = go0 ? r0 : r1;
-                continue;
-            }
-        }
-        if (st.empty()) break;
-        cur = st.pop();
-    }
-    // the ray's own far end counts as a competitor of the winner
-    redo = near_tie || (hit.prim >= 0 && ray.tmax < __builtin_huge_valf() && !(best * (1.0f + kNearTie) < ray.tmax));
-    return hit.prim >= 0;
-}
-
-// Ordered closest hit; when order could matter the query is repeated in reference order, bounded by twice the window
-// behind the winner the ordered pass found.
-template <class C>
-PTD bool closest_fast(const DevScene& sc, const RayD& ray, HitD& hit, bool& redo, uint32_t* lds_stack, C& wc) {
-    const RayPre pre = make_pre(sc, ray);
-    bool found;
-    if (pre.special)
-        found = closest_ordered_t<true>(sc, ray, pre, hit, redo, lds_stack, wc);
-    else
-        found = closest_ordered_t<false>(sc, ray, pre, hit, redo, lds_stack, wc);
-    if (redo) {
-        const float bound = hit.t * (1.0f + 2.0f * kNearTie);
-        if (pre.special)
-            found = closest_exact_t<true>(sc, ray, pre, bound, hit, lds_stack, wc);
-        else
-            found = closest_exact_t<false>(sc, ray, pre, bound, hit, lds_stack, wc);
-    }
-    return found;
-}
-
-// Any hit on the 2-wide layout.  The reference's distance bound is constant for this query, so the set of leaves it
-// reaches does not depend on the visit order: with identical box decisions and unconditional leaf visits this returns
-// exactly what the reference returns, whatever the order.  Two kinds of subtree are left out: a box that the ray enters
-// (all three slabs) beyond its far end, widened by the kNearTie window, and a box that it has left before its near end
-// (box_reaches_range).  Neither can hold a triangle that is accepted within the ray's range -- the same margin between
-// box and triangle distances that closest_ordered_t relies on -- so visiting them, as the reference does because its
-// test ignores the z slab's entry and exit, never changes the answer.
-template <bool SPECIAL, class C>
-PTD bool any_ordered_t(const DevScene& sc, const RayD& ray, const RayPre& pre, uint32_t* lds_stack, C& wc) {
-    uint32_t spill[kSpillDepth];
-    Stack st;
-    st.init(lds_stack, spill);
-    const float far_end = SPECIAL ? __builtin_huge_valf() : ray.tmax * (1.0f + kNearTie);  // NaN slabs: no extra skip
-    uint32_t cur = sc.wide_root;
-    for (;;) {
-        if (cur & kLeafBit) {
-            const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
-            for (uint32_t k = 0; k < count; ++k) {
-                V3 p0, e1, e2;
-                int32_t prim;
-                load_tri(sc, first + 1u + k, p0, e1, e2, prim);
-                wc.tri();
-                float t, u, v;
-                if (tri_hit(p0, e1, e2, ray.o, ray.d, ray.tmin, ray.tmax, t, u, v)) return true;
-            }
-        } else {
-            const float4* w = sc.wide + 4 * size_t(cur);
-            wc.node();
-            const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-            const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
-            bool go0 = true, go1 = true;
-            if (!(r0 & kLeafBit)) {
-                const BoxT b = box_decide<SPECIAL>(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, pre);
-                go0 = b.overlap && b.tn < ray.tmax && (SPECIAL || (b.order <= far_end && box_reaches_range(b, ray.tmin)));
-            }
-            if (!(r1 & kLeafBit)) {
-                const BoxT b = box_decide<SPECIAL>(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, pre);
-                go1 = b.overlap && b.tn < ray.tmax && (SPECIAL || (b.order <= far_end && box_reaches_range(b, ray.tmin)));
-            }
-            if (go0 && go1) {
-                // a leaf first (cheap, may end the query); otherwise the first-listed child, which the builder made the
-                // larger one for exactly this purpose (src/bvh.cpp:137-144)
-                const bool swap = (r1 & kLeafBit) && !(r0 & kLeafBit);
-                cur = swap ? r1 : r0;
-                st.push(swap ? r0 : r1);
-                continue;
-            }
-            if (go0 || go1) {
-                cur = go0 ? r0 : r1;
-                continue;
-            }
-        }
-        if (st.empty()) break;
-        cur = st.pop();
-    }
-    return false;
-}
-
-template <class C>
-PTD bool any_fast(const DevScene& sc, const RayD& ray, uint32_t* lds_stack, C& wc) {
-    const RayPre pre = make_pre(sc, ray);
-    if (pre.special) return any_ordered_t<true>(sc, ray, pre, lds_stack, wc);
-    return any_ordered_t<false>(sc, ray, pre, lds_stack, wc);
 }
 
 // ------------------------------------------------------------------------------------------------ self test

@@ -5,11 +5,12 @@
 //     idling until the slowest lane of the wave is done.
 // The ordered lanes (ClosestLane, AnyLane) navigate with the conservative slab test box_cheap and take the reference's
 // exact box decision once per visited leaf, on the leaf's parent box (why that is enough: traverse.h, above box_cheap);
-// near-tie detection and the accepted triangles are those of closest_ordered_t / any_ordered_t.  Deferred subtrees that
-// have fallen behind the best hit by the time they are popped are dropped without a fetch (DistStack).  Rays that need
-// the plain-division slab test ("special") and queries whose result could depend on the visit order are not handled
-// here; they are handed back to the caller (`defer`), which runs them through closest_fast / closest_exact_t / any_fast
-// in a follow-up kernel.
+// candidates are the triangles the reference would accept, and two candidates (or a candidate and the ray's far end)
+// within the kNearTie window of each other are flagged, because then the reference's visit order decides which one it
+// keeps.  Deferred subtrees that have fallen behind the best hit by the time they are popped are dropped without a fetch
+// (DistStack).  Rays that need the plain-division slab test ("special") and queries whose result could depend on the
+// visit order are not handled here; they are handed back to the caller (`defer`), which traces them in reference order
+// (closest_exact / closest_exact_t with a distance bound / any_exact) in a follow-up step.
 #pragma once
 
 #include "traverse.h"
@@ -28,7 +29,7 @@ constexpr uint32_t kRefillBelow = PT_REFILL_BELOW;   // fetch new rays once fewe
 constexpr uint32_t kMinBoxLanes = PT_MIN_BOX_LANES;  // leave the box phase for the triangle phase once fewer lanes than this have a box step to do
 
 // Deferred-ray marker "trace this ray with the plain reference-order routine" (otherwise a deferred ray carries a distance
-// bound >= 0, or +inf for the generic ordered query).
+// bound >= 0 up to which the reference order is replayed).
 constexpr float kDeferExact = -1.0f;
 
 PTD uint32_t lane_id() { return __lane_id(); }
@@ -75,7 +76,7 @@ struct ClosestLane {
 
     PTD void begin(const DevScene& sc, const RayD& ray, const RayPre& p) {
         pre = p;
-        cr.set(p);
+        cr.set(sc, p);
         tmax = ray.tmax;
         best = window = ray.tmax;
         near_tie = false;
@@ -97,27 +98,42 @@ struct ClosestLane {
         }
     }
 
-    // one 2-wide node: both child boxes through the conservative test, leaf children like interior ones; leaves first
-    // (they can only tighten the bound), otherwise the nearer child
+    // one navigation node: its (up to) four slots through the conservative test; the nearest one that can hold a candidate
+    // is visited next, the others are deferred in far-to-near order, each with its entry distance
     template <class C>
     PTD void inner(const DevScene& sc, DistStack& st, C& wc) {
-        const float4* w = sc.wide + 4 * size_t(cur);
+        const uint4* w = sc.qnodes + kWide * size_t(cur);
         wc.node();
-        const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-        const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
-        const BoxC b0 = box_cheap(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, cr);
-        const BoxC b1 = box_cheap(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, cr);
-        const bool go0 = cheap_go(b0, pre.tmin, window), go1 = cheap_go(b1, pre.tmin, window);
-        const float o0 = (r0 & kLeafBit) ? -__builtin_huge_valf() : b0.tn, o1 = (r1 & kLeafBit) ? -__builtin_huge_valf() : b1.tn;
-        if (go0 && go1) {
-            const bool swap = o1 < o0;
-            cur = swap ? r1 : r0;
-            st.push(swap ? r0 : r1, swap ? b0.tn : b1.tn);
-        } else if (go0 || go1) {
-            cur = go0 ? r0 : r1;
-        } else {
+        const uint4 c0 = w[0], c1 = w[1], c2 = w[2], c3 = w[3];
+        const float inf = __builtin_huge_valf();
+        const BoxC b0 = box_cheap(c0.x, c0.y, c0.z, cr), b1 = box_cheap(c1.x, c1.y, c1.z, cr);
+        const BoxC b2 = box_cheap(c2.x, c2.y, c2.z, cr), b3 = box_cheap(c3.x, c3.y, c3.z, cr);
+        float k0 = (c0.w != kEmptyRef && cheap_go(b0, pre.tmin, window)) ? b0.tn : inf;
+        float k1 = (c1.w != kEmptyRef && cheap_go(b1, pre.tmin, window)) ? b1.tn : inf;
+        float k2 = (c2.w != kEmptyRef && cheap_go(b2, pre.tmin, window)) ? b2.tn : inf;
+        float k3 = (c3.w != kEmptyRef && cheap_go(b3, pre.tmin, window)) ? b3.tn : inf;
+        uint32_t r0 = c0.w, r1 = c1.w, r2 = c2.w, r3 = c3.w;
+        auto order = [](float& ka, uint32_t& ra, float& kb, uint32_t& rb) {  // afterwards ka <= kb
+            const bool sw = kb < ka;
+            const float kt = sw ? kb : ka;
+            const uint32_t rt = sw ? rb : ra;
+            kb = sw ? ka : kb;
+            rb = sw ? ra : rb;
+            ka = kt;
+            ra = rt;
+        };
+        order(k0, r0, k1, r1);
+        order(k2, r2, k3, r3);
+        order(k0, r0, k2, r2);
+        order(k1, r1, k3, r3);
+        order(k1, r1, k2, r2);
+        if (k3 < inf) st.push(r3, k3);
+        if (k2 < inf) st.push(r2, k2);
+        if (k1 < inf) st.push(r1, k1);
+        if (k0 < inf)
+            cur = r0;
+        else
             next(st);
-        }
     }
 
     // a leaf: first the reference's own decision on the parent box (see box_cheap in traverse.h), then its triangles
@@ -178,7 +194,7 @@ struct AnyLane {
 
     PTD void begin(const DevScene& sc, const RayD& ray, const RayPre& p) {
         pre = p;
-        cr.set(p);
+        cr.set(sc, p);
         tmax = ray.tmax;
         far_end = ray.tmax * (1.0f + kNearTie);
         occluded = false;
@@ -191,24 +207,33 @@ struct AnyLane {
     // triangle, and tries a leaf's triangles only after the parent's exact test, returns what the reference returns.
     template <class C>
     PTD void inner(const DevScene& sc, Stack& st, C& wc) {
-        const float4* w = sc.wide + 4 * size_t(cur);
+        const uint4* w = sc.qnodes + kWide * size_t(cur);
         wc.node();
-        const float4 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-        const uint32_t r0 = as_u(w3.x), r1 = as_u(w3.y);
-        const BoxC b0 = box_cheap(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, cr);
-        const BoxC b1 = box_cheap(w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, cr);
-        const bool go0 = cheap_go(b0, pre.tmin, far_end), go1 = cheap_go(b1, pre.tmin, far_end);
-        if (go0 && go1) {
-            // a leaf first (cheap, may end the query); otherwise the first-listed child, which the builder made the larger
-            // one for exactly this purpose (src/bvh.cpp:137-144)
-            const bool swap = (r1 & kLeafBit) && !(r0 & kLeafBit);
-            cur = swap ? r1 : r0;
-            st.push(swap ? r0 : r1);
-        } else if (go0 || go1) {
-            cur = go0 ? r0 : r1;
-        } else {
-            next(st);
+        const uint4 c0 = w[0], c1 = w[1], c2 = w[2], c3 = w[3];
+        const bool g0 = c0.w != kEmptyRef && cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), pre.tmin, far_end);
+        const bool g1 = c1.w != kEmptyRef && cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), pre.tmin, far_end);
+        const bool g2 = c2.w != kEmptyRef && cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), pre.tmin, far_end);
+        const bool g3 = c3.w != kEmptyRef && cheap_go(box_cheap(c3.x, c3.y, c3.z, cr), pre.tmin, far_end);
+        // the order does not change the answer; slots are listed larger subtree first, as the builder orders children for
+        // exactly this query (src/bvh.cpp:137-144), so the first slot is visited first and the last one pushed first
+        uint32_t nxt = kDone;
+        if (g3) nxt = c3.w;
+        if (g2) {
+            if (nxt != kDone) st.push(nxt);
+            nxt = c2.w;
         }
+        if (g1) {
+            if (nxt != kDone) st.push(nxt);
+            nxt = c1.w;
+        }
+        if (g0) {
+            if (nxt != kDone) st.push(nxt);
+            nxt = c0.w;
+        }
+        if (nxt != kDone)
+            cur = nxt;
+        else
+            next(st);
     }
 
     template <class C>
@@ -433,7 +458,7 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
                 } else if (pre.special) {
                     state = kLaneDone;
                     defer = true;
-                    bound = Lane::kReferenceOrder ? kDeferExact : __builtin_huge_valf();
+                    bound = kDeferExact;
                     L.hit.prim = -1;
                 } else {
                     L.begin(sc, ray, pre);
