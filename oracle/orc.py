@@ -60,6 +60,8 @@ def lib():
         L = C.CDLL(path)
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.POINTER(SceneDesc)]
+        L.orc_scene_create_with_tree.restype = C.c_void_p
+        L.orc_scene_create_with_tree.argtypes = [C.POINTER(SceneDesc), C.c_size_t, c_f32p, c_u32p, c_u32p, c_u32p]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_bvh_num_nodes.restype = C.c_size_t
         L.orc_bvh_num_nodes.argtypes = [C.c_void_p]
@@ -106,7 +108,9 @@ def _f32(a):
 class Scene:
     """An oracle scene built from a pt_hip.scene.SceneData."""
 
-    def __init__(self, sd):
+    def __init__(self, sd, bvh=None):
+        """bvh = (nodes with fields lo, hi, first, count; prim_ids): traverse this tree instead of running the oracle's own
+        builder (for scenes of tens of millions of triangles)."""
         L = lib()
         self.sd = sd
         tri, lemit = sd.lights()
@@ -131,7 +135,14 @@ class Scene:
         d.tex_rgb = C.cast(arr, C.POINTER(c_f32p))
         d.width, d.height, d.fovy = sd.width, sd.height, sd.fovy
         d.eye, d.lookat, d.up = (C.c_float * 3)(*sd.eye), (C.c_float * 3)(*sd.lookat), (C.c_float * 3)(*sd.up)
-        self.h = L.orc_scene_create(C.byref(d))
+        if bvh is None:
+            self.h = L.orc_scene_create(C.byref(d))
+        else:
+            nodes, ids = bvh
+            boxes = np.ascontiguousarray(np.concatenate([nodes["lo"], nodes["hi"]], 1), np.float32)
+            first, count = np.ascontiguousarray(nodes["first"], np.uint32), np.ascontiguousarray(nodes["count"], np.uint32)
+            ids = np.ascontiguousarray(ids, np.uint32)
+            self.h = L.orc_scene_create_with_tree(C.byref(d), len(nodes), _p(boxes, c_f32p), _p(first, c_u32p), _p(count, c_u32p), _p(ids, c_u32p))
         self.n_lights = d.n_lights
 
     def close(self):

@@ -1005,6 +1005,36 @@ orc_scene* orc_scene_create(const orc_scene_desc* d) {
     return s;
 }
 
+/* Test hook, no counterpart in the reference: the same scene, but traversing a tree that was built elsewhere (nodes in the
+ * layout of bvh.h:13-45) instead of running the restated builder.  For scenes of tens of millions of triangles, where the
+ * single-threaded builder above takes minutes; that the two builders produce the same tree is asserted on smaller scenes. */
+orc_scene* orc_scene_create_with_tree(const orc_scene_desc* d, size_t n_nodes, const float* boxes, const uint32_t* first,
+                                      const uint32_t* count, const uint32_t* prim_ids) {
+    orc_scene_desc no_tris = *d;
+    no_tris.n_tris = 0; /* everything but the builder */
+    no_tris.n_lights = 0;
+    orc_scene* s = orc_scene_create(&no_tris);
+    s->vi.assign(d->vi, d->vi + 3 * size_t(d->n_tris));
+    s->ni.assign(d->ni, d->ni + 3 * size_t(d->n_tris));
+    s->ti.assign(d->ti, d->ti + 3 * size_t(d->n_tris));
+    s->mat_id.assign(d->mat_id, d->mat_id + d->n_tris);
+    s->light_of_tri.assign(d->n_tris, -1);
+    s->lights.resize(d->n_lights);
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
+        s->lights[i] = Light{d->light_tri[i], to_v3(d->light_lemit + 3 * i), tri_area(*s, d->light_tri[i])};
+        s->light_of_tri[d->light_tri[i]] = (int32_t)i;
+    }
+    s->nodes.resize(n_nodes);
+    for (size_t i = 0; i < n_nodes; ++i) {
+        s->nodes[i].box.lo = to_v3(boxes + 6 * i);
+        s->nodes[i].box.hi = to_v3(boxes + 6 * i + 3);
+        s->nodes[i].first = first[i];
+        s->nodes[i].count = count[i];
+    }
+    s->prim_ids.assign(prim_ids, prim_ids + d->n_tris);
+    return s;
+}
+
 void orc_scene_destroy(orc_scene* s) { delete s; }
 
 size_t orc_bvh_num_nodes(const orc_scene* s) { return s->nodes.size(); }

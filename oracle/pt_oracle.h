@@ -71,6 +71,10 @@ typedef struct orc_stats {
 enum { ORC_INTEGRATOR_PATH = 0, ORC_INTEGRATOR_NORMAL = 1, ORC_INTEGRATOR_ALBEDO = 2 };
 
 orc_scene* orc_scene_create(const orc_scene_desc* d);
+/* Test hook: the same scene over a tree built elsewhere (n_nodes nodes: 6 floats min,max each, first, count; prim_ids
+ * n_tris) instead of the restated builder's -- for scenes where the single-threaded build would take minutes. */
+orc_scene* orc_scene_create_with_tree(const orc_scene_desc* d, size_t n_nodes, const float* boxes, const uint32_t* first,
+                                      const uint32_t* count, const uint32_t* prim_ids);
 void       orc_scene_destroy(orc_scene* s);
 
 /* BVH as built by the restated sweep-SAH builder (bvh.cpp:99-234). */

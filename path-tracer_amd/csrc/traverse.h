@@ -29,7 +29,13 @@
 namespace ptd {
 
 constexpr int kBlock = 128;      // threads per workgroup of every traversal kernel
-constexpr int kLdsDepth = 24;    // stack entries per lane in LDS
+#ifndef PT_LDS_DEPTH
+#define PT_LDS_DEPTH 24
+#endif
+#ifndef PT_DIST_ROWS
+#define PT_DIST_ROWS 12
+#endif
+constexpr int kLdsDepth = PT_LDS_DEPTH;    // stack entries per lane in LDS
 constexpr int kSpillDepth = 72;  // further entries per lane in scratch
 constexpr int kMaxStack = kLdsDepth + kSpillDepth;
 
@@ -65,7 +71,7 @@ struct Stack {
 // the ray enters its box, so that a subtree that lies beyond the best hit by the time it is popped is dropped without
 // its node being fetched.  kDistRows entries per lane in LDS (references in rows [0, kDistRows), distances in rows
 // [kDistRows, 2 kDistRows) of a [row][lane] array), the rest in two private arrays.
-constexpr int kDistRows = 12;
+constexpr int kDistRows = PT_DIST_ROWS;
 constexpr int kDistSpill = kMaxStack - kDistRows;
 
 struct DistStack {

@@ -560,3 +560,53 @@ def test_full_size_bathroom_workload_properties():
     assert (se["closest_rays"], se["any_rays"]) == (sf["closest_rays"], sf["any_rays"])
     assert np.allclose(e, f, rtol=1e-4, atol=1e-5)
     g.close()
+
+
+def test_fifty_million_triangle_ultra_hd_workload_properties():
+    """The largest configuration in shape: the library stand-in tessellated to 49 M triangles (a 98 M-node tree, 34 levels)
+    at 3840x2160 (the sampler's 4096-wide grid).  The tree is built once, by the host builder; the oracle traverses the same
+    tree (its own single-threaded builder would take minutes here; that both builders produce the same tree is checked on
+    smaller scenes in test_host.py).  Checked: both traversal orders agree bit for bit on a million random rays and on
+    their occlusion flags, every 97th of them equals the oracle's answer, per-sample radiance agrees with the oracle, films
+    of disjoint sample ranges add up, and both modes trace the same paths."""
+    sd = synth.library_synth(detail=44, width=3840, height=2160)
+    assert sd.n_tris > 49_000_000
+    g = api.Scene(sd)
+    assert g.host.depth >= 30
+    o = orc.Scene(sd, bvh=(g.host.nodes, g.host.prim_ids))
+    rng = np.random.default_rng(44)
+    n = 1 << 20
+    org = rng.uniform([-1.9, 0.05, -1.4], [1.9, 2.55, 1.4], (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::1000, 2] = 0.0                                    # some axis-parallel rays (plain-division path)
+    rays = np.concatenate([org, d, np.zeros((n, 1), np.float32), np.full((n, 1), np.inf, np.float32)], 1).astype(np.float32)
+    he, hf = g.intersect(rays, api.TRAVERSE_EXACT), g.intersect(rays, api.TRAVERSE_FAST)
+    assert np.array_equal(he.view(np.uint32), hf.view(np.uint32))
+    assert (he["prim"] >= 0).mean() > 0.99
+    sub = slice(0, n, 97)
+    assert helpers.hits_equal(he[sub], o.intersect(rays[sub])).all()
+    rays[:, 7] = rng.uniform(0.05, 3.0, n).astype(np.float32)
+    oe, first = g.occluded(rays, api.TRAVERSE_EXACT)
+    assert np.array_equal(oe, g.occluded(rays, api.TRAVERSE_FAST)[0])
+    occ_w, first_w = o.occluded(rays[sub])
+    assert np.array_equal(oe[sub], occ_w) and np.array_equal(first[sub], first_w)
+    assert 0.05 < oe.mean() < 0.95
+
+    pix = np.stack([rng.integers(0, sd.width, 1500), rng.integers(0, sd.height, 1500)], 1).astype(np.int32)
+    smp = rng.integers(0, 4096, 1500).astype(np.uint32)
+    want = np.array([o.li(int(p[0]), int(p[1]), int(s))["rgb"] for p, s in zip(pix, smp)], np.float32)
+    got = g.li(pix, smp, traversal=api.TRAVERSE_FAST)[0]
+    err = np.abs(got - want).max(1) / (np.abs(want).max(1) + 1e-3)
+    assert (err < 1e-3).mean() >= 0.99
+
+    a, sa = g.render(0, 1, traversal=api.TRAVERSE_FAST)
+    b, sb = g.render(1, 2, traversal=api.TRAVERSE_FAST)
+    c, sc = g.render(0, 2, traversal=api.TRAVERSE_FAST)
+    assert sa["paths"] == 3840 * 2160
+    assert sa["closest_rays"] + sb["closest_rays"] == sc["closest_rays"] and sa["any_rays"] + sb["any_rays"] == sc["any_rays"]
+    assert np.allclose(a + b, c, rtol=1e-5, atol=1e-5)
+    e, se = g.render(0, 1, traversal=api.TRAVERSE_EXACT)
+    assert (se["closest_rays"], se["any_rays"]) == (sa["closest_rays"], sa["any_rays"])        # same hits, same paths
+    assert np.allclose(e, a, rtol=1e-4, atol=1e-5)
+    g.close()
