@@ -114,13 +114,16 @@ typedef struct pt_hit {
 /* Traversal modes.
  * EXACT replays the reference's visit order on the binary tree (src/bvh.cpp:26-86): pop, cull interior nodes with the
  * current max distance, never box-test leaves, accept t <= max, last accepted wins.
- * FAST is an ordered (near child first, distance-culled) traversal of a 2-wide node layout built from the same tree.
- * An interior box is entered only if the reference's own test accepts it and the ray's three-slab interval through it
- * can hold an acceptable triangle (the reference's test ignores the z slab's entry and exit when it compares with the
- * ray's range); a query is repeated in the reference's order whenever two candidates (or a candidate and the ray's far
- * end) lie within a 2^-13 relative distance of each other, so that the reported triangle, t, u and v are the
- * reference's in both modes; occlusion queries are order-independent by construction.  For occluded rays FAST reports
- * first_prim = -2 (the "first accepted triangle" is a property of the reference's visit order). */
+ * FAST is an ordered (nearest slot first, distance-culled) traversal of a 4-wide node layout collapsed from the same tree,
+ * with slot boxes quantised outwards to 16 bits.  Interior nodes are only navigated, with a conservative slab test; the
+ * reference's own box decision is taken once per visited leaf, on the leaf's parent box, which decides whether the
+ * reference reaches that leaf at all (its slab test, src/aabb.cpp:6-35, is monotone under box nesting: a ray that it
+ * accepts for a box it accepts for every enclosing box).  A query is repeated in the reference's order whenever two
+ * candidates (or a candidate and the ray's far end) lie within a 2^-13 relative distance of each other, and rays with a
+ * zero, tiny, huge or non-finite direction component are traced in the reference's order from the start, so that the
+ * reported triangle, t, u and v are the reference's in both modes; occlusion queries are order-independent by
+ * construction.  For occluded rays FAST reports first_prim = -2 (the "first accepted triangle" is a property of the
+ * reference's visit order). */
 enum { PT_TRAVERSE_EXACT = 0, PT_TRAVERSE_FAST = 1 };
 
 /* Integrators (src/integrator.cpp): MIS path tracer :45-141, shading normal :20-31, base colour :33-43. */
