@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Throughput of one path-traced frame on N MI355X GPUs of one node.
 
-A step is one frame: every pixel of the workload's camera, `spp` Sobol' samples per pixel per GPU, MIS path tracing,
-rendered through the C ABI (libpt_hip.so) into a device-resident film, followed for N > 1 by one RCCL reduce of the film.
-Weak scaling: rank k renders sample numbers [k*spp, (k+1)*spp), so N GPUs produce an N*spp frame.
+A step is one frame: every pixel of the workload's camera, `spp` Sobol' samples per pixel, MIS path tracing, rendered
+through the C ABI (libpt_hip.so) into device-resident films, followed for N > 1 by one RCCL reduce of the film.
+Strong scaling is the default for N > 1: the frame of --spp samples is split by sample number, rank k renders its
+contiguous share of [0, spp).  --scaling weak gives every rank --spp samples of its own (an N*spp frame).
+The tree is built once per node (rank 0) and handed to the other ranks through /dev/shm.
 
 Prints one JSON line (rank 0).  value = closest-hit + any-hit queries of all ranks per second, in Mrays/s.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -19,8 +23,8 @@ sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "python"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
-NODE_BYTES = {"exact": 32, "fast": 64}   # node record read per visit: binary node / 2-wide node
-TRI_BYTES = 48             # leaf-order triangle record {p0, e1, e2, prim}
+NODE_BYTES = {"exact": 32, "fast": 64}   # node record read per visit: binary node / 4-wide navigation node
+TRI_BYTES = 48             # leaf-array record: triangle {p0, e1, e2, prim} or leaf header (parent box)
 # streamed bytes per unit of each kernel besides the BVH records (layouts: path-tracer_amd/csrc/kernels.h)
 UNIT_BYTES = {
     "generate": 68 + 16 + 24,        # path state + hit written, radiance slot zeroed, 2 Sobol' dimensions x 3 table words
@@ -51,6 +55,39 @@ def load_workload(name):
     raise SystemExit("unknown workload " + name)
 
 
+def kernel_source_hash():
+    """Digest of the device sources: counter figures quoted from profiles/traffic.json are stale once it changes."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "path-tracer_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def shared_tree(sd, rank, world, barrier):
+    """The reference-topology tree of the scene, built once per node: rank 0 builds and writes it to /dev/shm, the other
+    ranks map it.  Returns (nodes, prim_ids) or None when there is only one rank (Scene builds its own)."""
+    if world == 1:
+        return None
+    import numpy as np
+    from pt_hip import api
+    stem = "/dev/shm/pt_bench_tree_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid())
+    if rank == 0:
+        nodes, ids, _ = api.build_bvh(np.ascontiguousarray(sd.verts, np.float32), np.ascontiguousarray(sd.vi, np.uint32))
+        np.save(stem + "_nodes.npy", nodes.view(np.uint32).reshape(-1, 8))
+        np.save(stem + "_ids.npy", ids)
+    barrier()
+    if rank != 0:
+        nodes = np.load(stem + "_nodes.npy", mmap_mode="r").reshape(-1).view(api.NODE_DTYPE)
+        ids = np.load(stem + "_ids.npy", mmap_mode="r")
+    tree = (np.ascontiguousarray(nodes), np.ascontiguousarray(ids))
+    barrier()
+    if rank == 0:
+        for f in (stem + "_nodes.npy", stem + "_ids.npy"):
+            os.remove(f)
+    return tree
+
+
 def cpu_baseline(sd, budget_s=15.0):
     """The oracle (a port of the reference algorithm) on the host cores, on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -74,18 +111,20 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("PT_BENCH_WORKLOAD", "library-synth"))
-    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU")
+    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel of the frame (per GPU with --scaling weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default): N GPUs share one frame of --spp samples; weak: every GPU renders --spp samples of its own")
     ap.add_argument("--traversal", choices=["exact", "fast"], default="fast")
     ap.add_argument("--split", choices=["spp", "tile"], default="spp",
-                    help="multi-GPU partition: spp = every rank renders --spp further samples of all pixels (weak scaling, the default); "
-                         "tile = the ranks share the 32x32 pixel blocks of one frame of --spp samples (strong scaling)")
+                    help="multi-GPU partition: spp = by Sobol' sample number (all pixels on every rank); "
+                         "tile = the ranks share the 32x32 pixel blocks of one frame of --spp samples (always strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from pt_hip import api
-    from pt_hip.dist import block_share, reduce_film, spp_range_weak
+    from pt_hip.dist import block_share, reduce_film, spp_range_strong, spp_range_weak
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -97,12 +136,15 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     sd, label = load_workload(a.workload)
-    scene = api.Scene(sd, device=local_rank)
+    scene = api.Scene(sd, device=local_rank, bvh=shared_tree(sd, rank, world, dist.barrier if world > 1 else None))
     film = torch.empty((sd.height + 4, sd.width + 4, 4), dtype=torch.float32, device="cuda:%d" % local_rank)
     mode = api.TRAVERSE_EXACT if a.traversal == "exact" else api.TRAVERSE_FAST
     tiles = a.split == "tile" and world > 1
-    s0, s1 = (0, a.spp) if tiles else spp_range_weak(rank, a.spp)
+    strong = tiles or a.scaling == "strong"
+    s0, s1 = (0, a.spp) if tiles else (spp_range_strong(rank, world, a.spp) if strong else spp_range_weak(rank, a.spp))
     share = block_share(rank, world) if tiles else (0, 0)
+    if s1 <= s0:
+        raise SystemExit("--spp %d leaves rank %d without samples" % (a.spp, rank))
 
     def step():
         st = scene.render_device(film.data_ptr(), s0, s1, traversal=mode, block=share)
@@ -152,38 +194,50 @@ def main():
             bvh[k] = {"nodes_per_ray": n_node, "tris_per_ray": n_tri}
             per_unit[k] += NODE_BYTES[a.traversal] * n_node + TRI_BYTES * n_tri
         achieved = units[dominant] * per_unit[dominant] / (kms[dominant] * 1e-3) / 1e9 if kms[dominant] > 0 else 0.0
-        # HBM-side bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be
-        # read from inside this process); the committed figure is quoted when it is for this workload and kernel
-        traffic, traffic_note, counters = None, None, None
+        # Hardware counters cannot be read from inside this process: what binds the dominant kernel comes from the committed
+        # rocprofv3 --pmc passes of the same workload and pass size (profiles/traffic.json), stamped with the digest of the
+        # device sources they were measured on; a different digest marks them stale.
+        counters, stale = {}, None
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s/%s" % (a.workload, a.traversal), {}).get("k_" + dominant)
-            if t and t["bytes_per_launch"]:
-                traffic, traffic_note = t["bytes_per_launch"], "%s; %s" % (t["source"], t["how"])
-                counters = {k: t[k] for k in ("valu_issue_frac", "lanes_per_valu_inst_frac", "l2_hit_rate") if k in t}
+            if t:
+                counters = t
+                stale = t.get("kernel_source_hash") != kernel_source_hash()
         except (OSError, ValueError, KeyError):
             pass
+        launch_s = kms[dominant] / max(kn[dominant], 1) * 1e-3
+        traffic = counters.get("bytes_per_launch")
+        valu, lanes = counters.get("valu_issue_frac"), counters.get("lanes_per_valu_inst_frac")
         out = {
             "metric": "Mrays/s", "value": rays_total / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if tiles else "weak",
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if "synth" in a.workload else "reference mesh, no textures",
             "config": {"workload": label, "integrator": "MIS path tracer, 32 bounces, Sobol'",
-                       "spp_per_frame" if tiles else "spp_per_gpu": a.spp, "traversal": a.traversal,
-                       "parallelism": ("32x32-block split x%d + 1 film reduce" if tiles else "spp-range x%d + 1 film reduce") % world},
+                       "spp_per_frame" if strong else "spp_per_gpu": a.spp, "traversal": a.traversal,
+                       "parallelism": (("32x32-block split x%d" if tiles else ("spp-range split of one frame x%d" if strong else "spp-range x%d, one frame share each"))
+                                       + " + 1 film reduce, tree built once per node") % world},
             "samples_per_s": paths_total / dt,
             "rays_per_path": rays_total / max(paths_total, 1.0),
             "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
             "kernel_launches_per_step": {k: v / a.steps for k, v in kn.items()},
             "bvh_records_per_ray": bvh,
-            "roofline": {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "traffic_source": traffic_note,
-                         # from the same committed counter pass: what the kernel is really bound by (VALU issue slots in use,
-                         # share of the 64 lanes active per VALU instruction, L2 hit rate)
-                         "counters": counters,
-                         "note": "achieved counts ALGORITHMIC bytes (records fetched by the traversal + queue entries); most of them are served by "
-                                 "L2 / Infinity Cache, not HBM, so the fraction can approach or exceed 1: compare with traffic", "algorithmic_bytes_per_launch": per_unit[dominant] * units[dominant] / max(kn[dominant], 1),
+            # The traversal kernels are not bound by HBM: the records they gather are served by L2 / Infinity Cache, and the
+            # time goes into VALU issue at partial lane occupancy and into waiting for dependent gathers.  `frac` is therefore
+            # the share of the vector ALU's lane throughput that does useful work (issue share x active lanes); the
+            # algorithmic-bytes figure the contract asks for is kept as `achieved` against the HBM peak, next to the bytes
+            # that really crossed the fabric.
+            "roofline": {"bound": "valu", "kernel": "k_" + dominant,
+                         "frac": (valu * lanes) if valu is not None and lanes is not None else None,
+                         "valu_issue_frac": valu, "lane_frac": lanes, "l2_hit_rate": counters.get("l2_hit_rate"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (fabric requests x 64 B)",
+                         "hbm_frac_measured": (traffic / counters["avg_launch_ms"] / 1e-3 / 1e9 / HBM_PEAK_GBS) if traffic and counters.get("avg_launch_ms") else None,
+                         "counters_source": counters.get("source"), "counters_how": counters.get("how"),
+                         "counters_measured_at": {k: counters.get(k) for k in ("git", "kernel_source_hash", "spp_per_pass", "avg_launch_ms")} if counters else None,
+                         "stale": stale,
+                         "algorithmic_bytes_per_launch": per_unit[dominant] * units[dominant] / max(kn[dominant], 1),
                          "bytes_per_unit": per_unit[dominant], "units_per_launch": units[dominant] / max(kn[dominant], 1),
-                         "avg_launch_ms": kms[dominant] / max(kn[dominant], 1)},
+                         "avg_launch_ms": launch_s * 1e3},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)

@@ -35,7 +35,7 @@ def test_block_partition_covers_every_block_once_and_evenly():
         assert ptdist.block_share(0, 1) == (0, 0) and ptdist.block_share(2, 4) == (2, 4)
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, scaling):
     for p in (os.path.join(ROOT, "path-tracer_amd", "python"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     import torch
@@ -43,34 +43,36 @@ def _worker(rank, world, port, out_path):
 
     import orc
     from pt_hip import synth
-    from pt_hip.dist import reduce_film, spp_range_weak
+    from pt_hip.dist import reduce_film, spp_range_strong, spp_range_weak
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sd = synth.cornell_box(48, 40)
     scene = orc.Scene(sd)
-    b, e = spp_range_weak(rank, 3)
+    total = 3 * world if scaling == "weak" else 5      # strong: one frame of 5 samples, shares of 3 and 2
+    b, e = spp_range_weak(rank, 3) if scaling == "weak" else spp_range_strong(rank, world, total)
     film, stats = scene.render(b, e, nthreads=2)
     t = torch.from_numpy(film)
     reduce_film(t, dst=0)
     rays = torch.tensor([stats["closest_rays"] + stats["any_rays"]], dtype=torch.float64)
     dist.all_reduce(rays)
     if rank == 0:
-        whole, wstats = scene.render(0, 3 * world, nthreads=2)
+        whole, wstats = scene.render(0, total, nthreads=2)
         np.savez(out_path, reduced=t.numpy(), whole=whole, rays=rays.numpy(), whole_rays=wstats["closest_rays"] + wstats["any_rays"])
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_sum_to_the_whole_frame(tmp_path):
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_ranks_sum_to_the_whole_frame(tmp_path, scaling):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "r.npz")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, scaling), nprocs=2, join=True)
     z = np.load(out)
     # same samples, summed in a different order
     assert np.allclose(z["reduced"], z["whole"], rtol=1e-5, atol=1e-5)

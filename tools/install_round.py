@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
-"""Copies the results of `tools/gpu_round.sh <tag>` from gpurun_out/ into profiles/ as r1_<letter>_*, replacing the files of
+"""Copies the results of `tools/gpu_round.sh <tag>` from gpurun_out/ into profiles/ as r2_<letter>_*, replacing the files of
 the previous letter, refreshes profiles/traffic.json from the counter passes and prints the figures the design notes quote.
 Usage: tools/install_round.py <tag> <new letter> <old letter>"""
-import glob, json, os, re, shutil, sys
+import glob, json, os, re, shutil, subprocess, sys
 tag, new, old = sys.argv[1:4]
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-pairs = [("%s_bench_%s.json" % (tag, k), "r1_%s_bench_%s.json" % (new, k)) for k in ("library_fast", "veach_fast", "veach_exact", "library_exact")]
-pairs += [("%s_prof_bench_library_fast.txt" % tag, "r1_%s_rocprof_bench_library_fast.txt" % new),
-          ("%s_prof_library_fast.txt" % tag, "r1_%s_rocprof_pmc_library512spp_fast.txt" % new),
-          ("%s_prof_veach_fast.txt" % tag, "r1_%s_rocprof_pmc_veach512spp_fast.txt" % new)]
+pairs = [("%s_bench_%s.json" % (tag, k), "r2_%s_bench_%s.json" % (new, k)) for k in ("library_fast", "veach_fast", "veach_exact", "library_exact")]
+pairs += [("%s_prof_bench_library_fast.txt" % tag, "r2_%s_rocprof_bench_library_fast.txt" % new),
+          ("%s_prof_library_fast.txt" % tag, "r2_%s_rocprof_pmc_library512spp_fast.txt" % new),
+          ("%s_prof_veach_fast.txt" % tag, "r2_%s_rocprof_pmc_veach512spp_fast.txt" % new)]
 if old != new:
-    for f in glob.glob(os.path.join(P, "r1_%s_bench_*.json" % old)) + glob.glob(os.path.join(P, "r1_%s_rocprof_*.txt" % old)):
+    for f in glob.glob(os.path.join(P, "r2_%s_bench_*.json" % old)) + glob.glob(os.path.join(P, "r2_%s_rocprof_*.txt" % old)):
         os.remove(f)
 for a, b in pairs:
     shutil.copy(os.path.join(G, a), os.path.join(P, b))
@@ -31,10 +31,14 @@ def calls(path, kern):
             return int(l.split()[1])
 
 
+sys.path.insert(0, R)
+import bench  # noqa: E402  (kernel_source_hash)
+stamp = {"git": subprocess.check_output(["git", "-C", R, "rev-parse", "--short", "HEAD"]).decode().strip(), "kernel_source_hash": bench.kernel_source_hash(),
+         "spp_per_pass": 512}
 t = {}
 for key, name, note in (("library-synth/fast", "library512spp", "gathers of 64-B lines are outside the guide's calibration (may read up to 2x low)"),
                         ("veach-mis/fast", "veach512spp", "the whole scene (0.3 MB of nodes and triangles) lives in L2, what reaches the fabric is queue traffic")):
-    rel = "profiles/r1_%s_rocprof_pmc_%s_fast.txt" % (new, name)
+    rel = "profiles/r2_%s_rocprof_pmc_%s_fast.txt" % (new, name)
     path = os.path.join(R, rel)
     t[key] = {}
     for kern in ("k_extend", "k_shadow", "k_generate", "k_shade"):
@@ -46,16 +50,17 @@ for key, name, note in (("library-synth/fast", "library512spp", "gathers of 64-B
             "how": "(TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum) x 64 B over the %d %s launches of one 512-spp pass (the size of the bench's passes); %s"
                    % (n, sym, note),
             "source": rel,
-            # SQ_INSTS_VALU x 4 cycles over the SIMD cycles of the launches (1024 SIMDs at 2.4 GHz); active lanes per VALU instruction
-            "valu_issue_frac": round(p1[4] * 4 / (p1[0] * 1e-6 * 2.4e9 * 1024), 3),
+            # SQ_INSTS_VALU x 4 cycles over the SIMD cycles of the launches (1024 SIMDs); active lanes per VALU instruction
+            "valu_issue_frac": round(p1[4] * 4 / 1024 / (v[1] / 8 * p1[0] / v[0]), 3),   # cycles of the launches: GRBM_GUI_ACTIVE over the 8 XCDs
             "lanes_per_valu_inst_frac": round(p2[6] / (p2[2] * 64), 3),
-            "l2_hit_rate": round(v[4] / (v[4] + v[5]), 3)}
+            "l2_hit_rate": round(v[4] / (v[4] + v[5]), 3),
+            "avg_launch_ms": round(v[0] / n * 1e-3, 4), **stamp}
         print(key, kern, t[key][kern]["bytes_per_launch"], t[key][kern]["valu_issue_frac"], t[key][kern]["lanes_per_valu_inst_frac"], t[key][kern]["l2_hit_rate"])
 json.dump(t, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 for k in ("library_fast", "veach_fast", "veach_exact", "library_exact"):
-    d = json.load(open(os.path.join(P, "r1_%s_bench_%s.json" % (new, k))))
+    d = json.load(open(os.path.join(P, "r2_%s_bench_%s.json" % (new, k))))
     r = d["roofline"]
     print(k, "Mrays/s %.0f" % d["value"], "samples/s %.3g" % d["samples_per_s"], "ms/step %.0f" % d["ms_per_step"], "| roofline", r["kernel"],
-          "frac %.3f" % r["frac"], "avg launch %.3f ms" % r["avg_launch_ms"], "bytes/unit %.0f" % r["bytes_per_unit"], "units/launch %.3g" % r["units_per_launch"],
+          "frac", r["frac"], "stale", r["stale"], "avg launch %.3f ms" % r["avg_launch_ms"], "bytes/unit %.0f" % r["bytes_per_unit"], "units/launch %.3g" % r["units_per_launch"],
           "| cpu", d.get("cpu_baseline", {}).get("value"))
-print(open(os.path.join(P, "r1_%s_rocprof_bench_library_fast.txt" % new)).read().split("\n")[2])
+print(open(os.path.join(P, "r2_%s_rocprof_bench_library_fast.txt" % new)).read().split("\n")[2])
