@@ -131,9 +131,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
+    # PT_BENCH_REHEARSE=1: ranks share whatever GPUs there are and reduce through gloo and host memory -- a dry run of the
+    # multi-rank code path on a box with fewer GPUs than ranks (its numbers mean nothing)
+    rehearse = os.environ.get("PT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     sd, label = load_workload(a.workload)
     scene = api.Scene(sd, device=local_rank, bvh=shared_tree(sd, rank, world, dist.barrier if world > 1 else None))
@@ -148,7 +156,12 @@ def main():
 
     def step():
         st = scene.render_device(film.data_ptr(), s0, s1, traversal=mode, block=share)
-        reduce_film(film, dst=0)
+        if rehearse and world > 1:
+            host = film.cpu()
+            reduce_film(host, dst=0)
+            film.copy_(host)
+        else:
+            reduce_film(film, dst=0)
         if world > 1:
             torch.cuda.synchronize()   # the next step clears the film on the renderer's own stream: the reduce must be done with it
         return st
@@ -167,7 +180,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt, float(sum(s["closest_rays"] + s["any_rays"] for s in stats)), float(sum(s["paths"] for s in stats))],
-                     dtype=torch.float64, device="cuda")
+                     dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
