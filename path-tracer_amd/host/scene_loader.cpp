@@ -105,8 +105,12 @@ void load_mtl(const std::string& path, pt_host_scene& s) {
             std::string tex, tok;
             while (is >> tok) tex = tok;
             int32_t id = -1;
-            if (!load_texture(folder_of(path) + tex, s, id))
-                throw std::runtime_error("Fail to load image file: \"" + folder_of(path) + tex + "\"! (binary PPM/PFM textures only)");
+            // the reference's scenes name JPG / PNG files; tools/convert_textures.py writes <stem>.ppm next to them
+            const std::string full = folder_of(path) + tex;
+            const size_t dot = full.find_last_of('.');
+            const std::string stem = dot == std::string::npos ? full : full.substr(0, dot);
+            if (!load_texture(full, s, id) && !load_texture(stem + ".ppm", s, id) && !load_texture(stem + ".pfm", s, id))
+                throw std::runtime_error("Fail to load image file: \"" + full + "\"! (binary PPM/PFM textures only; see tools/convert_textures.py)");
             s.mats[cur].tex = id;
         }
     }

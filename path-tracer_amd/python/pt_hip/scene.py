@@ -121,6 +121,27 @@ class SceneData:
 
 # ----------------------------------------------------------------------------- loaders (reference file formats)
 
+def srgb_to_linear(v):
+    """Color3f::toLinearRGB (include/pt/color.h:70-83) in float32."""
+    v = np.asarray(v, np.float32)
+    hi = np.power((v + np.float32(0.055)) * np.float32(1.0 / 1.055), np.float32(2.4), dtype=np.float32)
+    return np.where(v <= np.float32(0.04045), v * np.float32(1.0 / 12.92), hi).astype(np.float32)
+
+
+def load_image_linear(path):
+    """Bitmap::load (src/bitmap.cpp:68-93): the file's 8-bit samples / 255, sRGB -> linear, the first three channels of every
+    pixel; rows top to bottom, no flip.  The reference decodes with stb_image keeping the file's channel count; PIL gives
+    the same samples for 8-bit RGB / RGBA files (JPEG decoders may differ in the last bit of a sample).  Images with fewer
+    than three channels, which the reference would read out of step (it takes three consecutive bytes per pixel whatever
+    the channel count), are expanded to grey RGB instead."""
+    from PIL import Image
+    with Image.open(path) as im:
+        if im.mode not in ("RGB", "RGBA"):
+            im = im.convert("RGBA" if "A" in im.mode or "transparency" in im.info else "RGB")
+        a = np.asarray(im, np.uint8)[..., :3]
+    return srgb_to_linear(a.astype(np.float32) / np.float32(255.0))
+
+
 def load_mtl(path):
     """Subset of MTL used by the reference (src/scene.cpp:87-110): Kd, Ks, Ns, map_Kd."""
     mats = []
@@ -217,13 +238,26 @@ def load_xml(path):
 
 
 def load_scene_dir(folder, name=None):
+    """A scene directory in the reference's layout (<name>.obj + .mtl + .xml, textures named by map_Kd relative to the .mtl,
+    src/scene.cpp:23-177).  A map_Kd file that cannot be read raises, as Scene::loadOBJ does."""
     name = name or os.path.basename(os.path.normpath(folder))
     verts, normals, uvs, vi, ni, ti, mat_id, mats = load_obj(os.path.join(folder, name + ".obj"))
     cam = load_xml(os.path.join(folder, name + ".xml"))
     if (mat_id < 0).any():
         raise ValueError("face without material")
+    textures, mat_tex, seen = [], np.full(len(mats), -1, np.int32), {}
+    for i, m in enumerate(mats):
+        if m["map_Kd"]:
+            tex_path = os.path.join(folder, m["map_Kd"].replace("\\", "/"))
+            if tex_path not in seen:
+                try:
+                    textures.append(load_image_linear(tex_path))
+                except OSError as e:
+                    raise ValueError('Fail to load image file: "%s"! (%s)' % (tex_path, e))
+                seen[tex_path] = len(textures) - 1
+            mat_tex[i] = seen[tex_path]
     return SceneData(
         name=name, verts=verts, normals=normals, uvs=uvs, vi=vi, ni=ni, ti=ti, mat_id=mat_id.astype(np.uint32),
         mat_names=[m["name"] for m in mats], mat_kd=np.asarray([m["Kd"] for m in mats], np.float32).reshape(-1, 3),
         mat_ks=np.asarray([m["Ks"] for m in mats], np.float32).reshape(-1, 3),
-        mat_ns=np.asarray([m["Ns"] for m in mats], np.float32), mat_tex=np.full(len(mats), -1, np.int32), **cam)
+        mat_ns=np.asarray([m["Ns"] for m in mats], np.float32), mat_tex=mat_tex, textures=textures, **cam)

@@ -301,12 +301,24 @@ def _procedural_textures():
     return [np.clip(t, 0.0, 1.0).astype(np.float32) for t in (tiles, marble, wood, rug, pic)]
 
 
-def bathroom_synth(detail=9, width=768, height=768):
+def bathroom_textures(texture_dir):
+    """The bathroom's own texture images from a copy of the reference's scenes/bathroom/textures (floor_tiles.png,
+    marble.jpg, wood.jpg, picture1.jpg; rug.png is not in the reference's tree, the procedural rug stands in), decoded the
+    way Bitmap::load does (scene.load_image_linear).  Order: tiles, marble, wood, rug, picture."""
+    import os
+    from .scene import load_image_linear
+    proc = _procedural_textures()
+    files = ("floor_tiles.png", "marble.jpg", "wood.jpg", None, "picture1.jpg")
+    return [proc[i] if f is None else load_image_linear(os.path.join(texture_dir, f)) for i, f in enumerate(files)]
+
+
+def bathroom_synth(detail=9, width=768, height=768, texture_dir=None):
     """Stand-in for the reference's bathroom scene, whose mesh is not in its tree: a tiled room with a tub, a vanity, a
     glossy wall panel, spheres and cylinders-as-prisms of the metal materials, a rug and a picture, lit by one ceiling panel.
     Camera and light are those of scenes/bathroom/bathroom.xml; material values are taken from bathroom.mtl (Floor, Marble,
     Wood, Rug, Painting1 textured; Mirror, StainlessSmooth, StainlessRough, Bathtube, GreyWall, Light untextured); the
-    texture images are procedural.  Triangle count grows with detail^2 (detail 9: about 0.47 M)."""
+    texture images are procedural unless texture_dir names a copy of the reference's scenes/bathroom/textures
+    (bathroom_textures).  Triangle count grows with detail^2 (detail 9: about 0.47 M)."""
     TILES, MARBLE, WOODT, RUGT, PIC = range(5)
     mats = [("Floor", (0, 0, 0), (0, 0, 0), 4.0, TILES), ("Marble", (0.5, 0.5, 0.5), (0, 0, 0), 1.0, MARBLE),
             ("Wood", (0, 0, 0), (0, 0, 0), 6.0, WOODT), ("Rug", (0.5, 0.5, 0.5), (0, 0, 0), 1.0, RUGT),
@@ -364,5 +376,6 @@ def bathroom_synth(detail=9, width=768, height=768):
                eye=tuple(float(np.float32(x)) for x in (0.0072405338287353516, 0.9124049544334412, -0.2275838851928711)),
                lookat=tuple(float(np.float32(x)) for x in (-2.787562608718872, 0.9699121117591858, -2.6775901317596436)), up=(0.0, 1.0, 0.0))
     return _scene("bathroom-synth", np.concatenate(V), np.concatenate(T), np.concatenate(M), [m[:4] for m in mats], [("Light", (30.0, 30.0, 30.0))],
-                  cam, uvs=np.concatenate(U), ti=np.concatenate(TI), mat_tex=[m[4] for m in mats], textures=_procedural_textures())
+                  cam, uvs=np.concatenate(U), ti=np.concatenate(TI), mat_tex=[m[4] for m in mats],
+                  textures=_procedural_textures() if texture_dir is None else bathroom_textures(texture_dir))
 

@@ -314,12 +314,24 @@ def test_li_ray_log_and_dimensions(veach_oracle):
     assert np.isfinite(r["rgb"]).all() and (r["rgb"] >= 0).all()
 
 
-def test_texture_lookup_against_numpy_restatement():
+REF_TEXTURES = "/root/reference/scenes/bathroom/textures"
+
+
+@pytest.mark.parametrize("which", ["procedural", "reference files"])
+def test_texture_lookup_against_numpy_restatement(which):
     """Base-colour AOV samples on the textured floor / wall against an independent numpy version of Bitmap::sample
     (src/bitmap.cpp:146-166: clamp to [0,1], s = max(u*cols - 0.5, 0), bilinear with clamped upper texel, no flip) fed
-    with the uv interpolation of Intersection::complete (src/shape.cpp:163-165)."""
+    with the uv interpolation of Intersection::complete (src/shape.cpp:163-165).  Second case: the bathroom stand-in with
+    the reference's own texture files (JPG / PNG, non-square), decoded as Bitmap::load does.  Parity of this row stays
+    unpinned by the reference: it holds no reproducible image of a textured scene (the bathroom mesh is not in its tree)."""
     from pt_hip import synth
-    sd = synth.textured_room()
+    if which == "procedural":
+        sd = synth.textured_room()
+    else:
+        if not os.path.isdir(REF_TEXTURES):
+            pytest.skip("reference tree not present")
+        sd = synth.bathroom_synth(detail=1, width=96, height=96, texture_dir=REF_TEXTURES)
+        assert sd.textures[1].shape == (1454, 2048, 3) and sd.textures[0].shape == (1024, 996, 3)
     o = orc.Scene(sd)
 
     def sample(tex, uv):
@@ -353,6 +365,51 @@ def test_texture_lookup_against_numpy_restatement():
             assert np.allclose(got, want, rtol=2e-5, atol=2e-6), (px, py, prim, got, want)
             checked += 1
     assert checked > 50
+
+
+def test_reference_texture_files_are_decoded_like_bitmap_load(tmp_path):
+    """Bitmap::load (src/bitmap.cpp:68-93): 8-bit samples / 255 then Color3f::toLinearRGB (include/pt/color.h:70-83), rows
+    top to bottom.  The decoder of the Python loader against a scalar restatement on the file's raw samples, through
+    load_scene_dir on a scene whose .mtl names the reference's own files with map_Kd, and through the PPM that
+    tools/convert_textures.py writes for the C++ front end."""
+    import math
+    import subprocess
+    import sys
+    from PIL import Image
+    from conftest import ROOT
+    from pt_hip import scene, synth
+    if not os.path.isdir(REF_TEXTURES):
+        pytest.skip("reference tree not present")
+    sd = synth.cornell_box(32, 32)
+    tmp_path = tmp_path / "room"                   # export_dir writes <root>/<name>/<name>.*
+    sd.export_dir(str(tmp_path.parent), "room")
+    with open(tmp_path / "room.mtl", "a") as f:
+        f.write("\nnewmtl Tiled\nKd 0 0 0\nmap_Kd textures/floor_tiles.png\nnewmtl Wooden\nKd 0 0 0\nmap_Kd textures/wood.jpg\n"
+                "newmtl Wooden2\nKd 0 0 0\nmap_Kd textures/wood.jpg\n")
+    os.symlink(REF_TEXTURES, tmp_path / "textures")
+    got = scene.load_scene_dir(str(tmp_path), "room")
+    assert list(got.mat_tex[-3:]) == [0, 1, 1] and (got.mat_tex[:-3] == -1).all() and len(got.textures) == 2
+    for tex, name in zip(got.textures, ("floor_tiles.png", "wood.jpg")):
+        raw = np.asarray(Image.open(os.path.join(REF_TEXTURES, name)).convert("RGB"))
+        assert tex.shape == raw.shape and tex.dtype == np.float32
+        rng = np.random.default_rng(1)
+        for y, x in zip(rng.integers(0, raw.shape[0], 300), rng.integers(0, raw.shape[1], 300)):
+            for c in range(3):
+                v = np.float32(raw[y, x, c]) / np.float32(255.0)
+                want = v * np.float32(1.0 / 12.92) if v <= np.float32(0.04045) else np.float32(
+                    math.pow(float((v + np.float32(0.055)) * np.float32(1.0 / 1.055)), 2.4))
+                assert abs(float(tex[y, x, c]) - float(want)) <= 5e-7 * max(float(want), 1e-3)      # a few ulps: powf against pow
+    # a map_Kd file that is not there fails like the reference does
+    with open(tmp_path / "room.mtl", "a") as f:
+        f.write("newmtl Rugged\nmap_Kd textures/rug.png\n")
+    with pytest.raises(ValueError, match="Fail to load image file"):
+        scene.load_scene_dir(str(tmp_path), "room")
+    out = tmp_path / "ppm"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "convert_textures.py"), str(tmp_path), "room.mtl", "--out", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "missing:" in r.stdout, r.stdout + r.stderr
+    ppm = open(out / "textures" / "floor_tiles.ppm", "rb").read()
+    assert ppm.startswith(b"P6\n996 1024\n255\n") and len(ppm) == len(b"P6\n996 1024\n255\n") + 996 * 1024 * 3
 
 
 @pytest.mark.parametrize("rho", [0.5, 0.8])
