@@ -185,6 +185,17 @@ int pt_hip_scene_create(const pt_scene_desc* desc, pt_hip_scene** out);
 /* Replaces `delete m_accel` in Scene::~Scene (include/pt/scene.h:18-26): frees device copies only. */
 int pt_hip_scene_destroy(pt_hip_scene* scene);
 
+/* BVHTree::build + BVHTreeBuilder::build (src/bvh.cpp:13-24, 99-234; include/pt/bvh.h:63-116) on the GPU: the same tree,
+ * node for node, as the reference's sequential builder (and as pt_host_build_bvh) -- all ranges of a tree level are split
+ * at once with segmented scans, the node numbers of the reference's stack order are replayed afterwards; only the three
+ * initial std::sort calls stay on the host (their order among equal keys is a property of that algorithm).
+ * verts: 3 floats per vertex; vi: 3 one-based vertex indices per triangle.  On success *nodes (n_nodes entries) and
+ * *prim_ids (n_tris entries) are malloc'd: release with pt_hip_free.  max_depth (nullable): height of the tree, root = 1.
+ * Needs pt_hip_init. */
+int pt_hip_build_bvh(const float* verts, uint32_t n_verts, const uint32_t* vi, uint32_t n_tris, pt_bvh_node** nodes, uint32_t* n_nodes,
+                     uint32_t** prim_ids, uint32_t* max_depth);
+void pt_hip_free(void* p);
+
 /* ---- batched ray queries (the Accel interface, include/pt/accel.h:10-24) ------------------------------------------ */
 
 /* Accel::rayIntersect(const Ray&, Intersection&) -> BVHTree::rayIntersect (src/bvh.cpp:26-59), n rays at once.

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "host_common.h"
 #include "kernels.h"
 #include "pt_hip.h"
 #include "sobol_tables.inc"
@@ -886,6 +887,12 @@ int prepare_split(pt_hip_scene* s, uint32_t rank, uint32_t count, uint32_t tiles
 }
 
 }  // namespace
+
+namespace pth {
+int fail(int code, const std::string& msg) { return ::fail(code, msg); }
+hipStream_t stream() { return g_stream; }
+int device() { return g_device; }
+}  // namespace pth
 
 // ======================================================================================================== C ABI
 

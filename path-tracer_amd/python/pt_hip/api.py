@@ -120,6 +120,8 @@ def hip_lib():
         L.pt_hip_li.argtypes = [C.c_void_p, C.POINTER(RenderParams), c_i32p, c_u32p, C.c_size_t, c_f32p, c_f32p, C.POINTER(Stats)]
         L.pt_hip_sobol.argtypes = [C.c_void_p, c_i32p, c_u32p, c_u32p, C.c_size_t, c_f32p]
         L.pt_hip_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.pt_hip_build_bvh.argtypes = [c_f32p, C.c_uint32, c_u32p, C.c_uint32, C.POINTER(C.POINTER(BvhNode)), c_u32p, C.POINTER(c_u32p), c_u32p]
+        L.pt_hip_free.argtypes = [C.c_void_p]
         _hip = L
     return _hip
 
@@ -154,6 +156,24 @@ def build_bvh(verts, vi):
     ids = np.ctypeslib.as_array(ids_p, shape=(len(vi),)).copy()
     L.pt_host_free(nodes_p)
     L.pt_host_free(ids_p)
+    return nodes, ids, depth.value
+
+
+def build_bvh_gpu(verts, vi, device=0):
+    """The same tree from pt_hip_build_bvh (segmented-scan sweep-SAH on the GPU)."""
+    init(device)
+    verts = np.ascontiguousarray(verts, np.float32)
+    vi = np.ascontiguousarray(vi, np.uint32)
+    L = hip_lib()
+    nodes_p, ids_p = C.POINTER(BvhNode)(), c_u32p()
+    n_nodes, depth = C.c_uint32(), C.c_uint32()
+    _chk(L.pt_hip_build_bvh(_p(verts, c_f32p), len(verts), _p(vi, c_u32p), len(vi), C.byref(nodes_p), C.byref(n_nodes), C.byref(ids_p),
+                            C.byref(depth)))
+    words = np.ctypeslib.as_array(C.cast(nodes_p, c_u32p), shape=(n_nodes.value * (C.sizeof(BvhNode) // 4),))
+    nodes = words.copy().view(NODE_DTYPE)
+    ids = np.ctypeslib.as_array(ids_p, shape=(len(vi),)).copy()
+    L.pt_hip_free(nodes_p)
+    L.pt_hip_free(ids_p)
     return nodes, ids, depth.value
 
 

@@ -610,3 +610,22 @@ def test_fifty_million_triangle_ultra_hd_workload_properties():
     assert (se["closest_rays"], se["any_rays"]) == (sa["closest_rays"], sa["any_rays"])        # same hits, same paths
     assert np.allclose(e, a, rtol=1e-4, atol=1e-5)
     g.close()
+
+
+# ------------------------------------------------------------------------------------------------ tree build on the GPU
+
+@pytest.mark.parametrize("make", [lambda: synth.random_soup(1, seed=1), lambda: synth.random_soup(2, seed=5), lambda: synth.random_soup(7, seed=2),
+                                  lambda: synth.random_soup(3000, seed=3), lambda: synth.grid_plane(16), synth.cornell_box, synth.textured_room,
+                                  lambda: synth.library_synth(detail=1), lambda: synth.library_synth(detail=4),
+                                  lambda: synth.bathroom_synth(detail=2, width=64, height=64), "veach"])
+def test_gpu_tree_build_equals_the_host_builder_node_for_node(make, veach_sd):
+    """pt_hip_build_bvh (all ranges of a level split at once with segmented scans, numbering replayed) against
+    pt_host_build_bvh (the reference's sequential loop, itself equal to the oracle's builder: tests/test_host.py): every
+    node's box, child index / leaf range, the triangle order and the depth, bit for bit.  grid_plane and the tessellated
+    rooms are full of equal centroid coordinates and equally cheap split candidates."""
+    sd = veach_sd if make == "veach" else make()
+    want_nodes, want_ids, want_depth = api.build_bvh(sd.verts, sd.vi)
+    nodes, ids, depth = api.build_bvh_gpu(sd.verts, sd.vi)
+    assert len(nodes) == len(want_nodes) and depth == want_depth
+    assert np.array_equal(ids, want_ids)
+    assert np.array_equal(nodes.view(np.uint32), want_nodes.view(np.uint32))

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build/var_$name
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -Wno-unused-function \
-    -Iinclude -Ibuild "$@" -shared -o build/var_$name/libpt_hip.so path-tracer_amd/csrc/pt_hip.hip
+    -Iinclude -Ibuild "$@" -shared -o build/var_$name/libpt_hip.so path-tracer_amd/csrc/pt_hip.hip build/obj/bvh_build.o
 cp path-tracer_amd/lib/libpt_host.so build/var_$name/
