@@ -64,7 +64,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def shared_tree(sd, rank, world, barrier):
+def shared_tree(sd, rank, world, barrier, device=0):
     """The reference-topology tree of the scene, built once per node: rank 0 builds and writes it to /dev/shm, the other
     ranks map it.  Returns (nodes, prim_ids) or None when there is only one rank (Scene builds its own)."""
     if world == 1:
@@ -73,7 +73,7 @@ def shared_tree(sd, rank, world, barrier):
     from pt_hip import api
     stem = "/dev/shm/pt_bench_tree_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid())
     if rank == 0:
-        nodes, ids, _ = api.build_bvh(np.ascontiguousarray(sd.verts, np.float32), np.ascontiguousarray(sd.vi, np.uint32))
+        nodes, ids, _ = api.build_bvh_gpu(np.ascontiguousarray(sd.verts, np.float32), np.ascontiguousarray(sd.vi, np.uint32), device=device)
         np.save(stem + "_nodes.npy", nodes.view(np.uint32).reshape(-1, 8))
         np.save(stem + "_ids.npy", ids)
     barrier()
@@ -144,7 +144,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     sd, label = load_workload(a.workload)
-    scene = api.Scene(sd, device=local_rank, bvh=shared_tree(sd, rank, world, dist.barrier if world > 1 else None))
+    scene = api.Scene(sd, device=local_rank, bvh=shared_tree(sd, rank, world, dist.barrier if world > 1 else None, local_rank))
     film = torch.empty((sd.height + 4, sd.width + 4, 4), dtype=torch.float32, device="cuda:%d" % local_rank)
     mode = api.TRAVERSE_EXACT if a.traversal == "exact" else api.TRAVERSE_FAST
     tiles = a.split == "tile" and world > 1

@@ -89,7 +89,8 @@ typedef struct pt_scene_desc {
     const pt_light*    lights;
     const pt_texture*  textures;
     pt_camera          camera;
-    const pt_bvh_node* nodes;    /* n_nodes, root = 0 */
+    const pt_bvh_node* nodes;    /* n_nodes, root = 0; NULL with n_nodes == 0 and prim_ids == NULL: pt_hip_scene_create builds
+                                    the reference's tree itself (pt_hip_build_bvh) */
     const uint32_t*    prim_ids; /* n_tris: leaf order -> triangle index (BVHTree::m_prim_ids) */
 } pt_scene_desc;
 

@@ -9,9 +9,11 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_common.h"
@@ -236,64 +238,150 @@ int validate(const pt_scene_desc* d, uint32_t& depth_out) {
     return PT_OK;
 }
 
+// f(begin, end) over [0, n) on up to 16 threads
+template <typename F>
+void parallel_for(size_t n, F f) {
+    const size_t hw = std::max<size_t>(1, std::min<size_t>(16, std::thread::hardware_concurrency()));
+    const size_t parts = std::min(hw, (n + 4095) / 4096);
+    if (parts <= 1) {
+        f(size_t(0), n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < parts; ++k) th.emplace_back([=] { f(n * k / parts, n * (k + 1) / parts); });
+    f(size_t(0), n / parts);
+    for (std::thread& t : th) t.join();
+}
+
+// Builds a device array out of `n_units` units of variable size: unit u occupies items [offset(u), offset(u + 1)) and is
+// written by fill(u, out).  The array is produced in chunks of a few million items: worker threads fill one pinned staging
+// buffer while the previous one is on its way to the device, so neither the fill nor the copy of a multi-gigabyte array
+// runs on one thread or through pageable memory.
+template <typename T, typename Offset, typename Fill>
+int fill_upload(pt_hip_scene* s, size_t n_units, Offset offset, const T** dst, Fill fill) {
+    const size_t total = offset(n_units);
+    void* dv = nullptr;
+    HIP_TRY(hipMalloc(&dv, std::max<size_t>(total, 1) * sizeof(T)));
+    s->owned.push_back(dv);
+    *dst = static_cast<const T*>(dv);
+    if (total == 0) return PT_OK;
+    const size_t chunk_items = std::max<size_t>(1, (size_t(32) << 20) / sizeof(T));
+    size_t largest = 0;  // the staging buffers hold a whole number of units
+    {
+        size_t u = 0;
+        while (u < n_units) {
+            size_t v = u + 1;
+            while (v < n_units && offset(v + 1) - offset(u) <= chunk_items) ++v;
+            largest = std::max(largest, offset(v) - offset(u));
+            u = v;
+        }
+    }
+    T* stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    auto cleanup = [&] {
+        for (int k = 0; k < 2; ++k) {
+            if (stage[k]) (void)hipHostFree(stage[k]);
+            if (done[k]) (void)hipEventDestroy(done[k]);
+        }
+    };
+    for (int k = 0; k < 2; ++k) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&stage[k]), largest * sizeof(T), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&done[k], hipEventDisableTiming) != hipSuccess) {
+            cleanup();
+            return fail(PT_ERR_DEVICE, "no pinned staging memory for the scene upload");
+        }
+    }
+    int rc = PT_OK;
+    size_t u = 0;
+    for (int k = 0; u < n_units && rc == PT_OK; k ^= 1) {
+        size_t v = u + 1;
+        while (v < n_units && offset(v + 1) - offset(u) <= chunk_items) ++v;
+        const size_t first = offset(u), items = offset(v) - first;
+        if (hipEventSynchronize(done[k]) != hipSuccess) rc = fail(PT_ERR_DEVICE, "scene upload failed");  // the copy that last used this buffer
+        T* out = stage[k];
+        parallel_for(v - u, [&](size_t b, size_t e) {
+            for (size_t x = u + b; x < u + e; ++x) fill(x, out + (offset(x) - first));
+        });
+        if (rc == PT_OK && (hipMemcpyAsync(static_cast<T*>(dv) + first, out, items * sizeof(T), hipMemcpyHostToDevice, g_stream) != hipSuccess ||
+                            hipEventRecord(done[k], g_stream) != hipSuccess))
+            rc = fail(PT_ERR_DEVICE, "scene upload failed");
+        u = v;
+    }
+    if (hipStreamSynchronize(g_stream) != hipSuccess && rc == PT_OK) rc = fail(PT_ERR_DEVICE, "scene upload failed");
+    cleanup();
+    return rc;
+}
+
+// phase times of pt_hip_scene_create on stderr when PT_HIP_SCENE_TIMING is set
+struct PhaseClock {
+    bool on = std::getenv("PT_HIP_SCENE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "pt_hip_scene_create: %-28s %.2f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+
 int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     DevScene& dev = s->dev;
+    PhaseClock clk;
     // Leaf array: every leaf is a header record (its parent's box, see leaf_parent_accepts) followed by its triangles
     // {p0, prim} {e1} {e2}; slot_of[i] = header slot of leaf node i.
-    std::vector<uint32_t> slot_of(d->n_nodes, 0), parent(d->n_nodes, 0);
-    uint32_t n_slots = 0;
+    // (slot_of has one entry more than there are nodes: the slots of nodes [0, i) -- interior nodes take none)
+    std::vector<uint32_t> slot_of(size_t(d->n_nodes) + 1, 0), parent(d->n_nodes, 0);
+    uint64_t n_slots64 = 0;
     for (uint32_t i = 0; i < d->n_nodes; ++i) {
         const pt_bvh_node& b = d->nodes[i];
-        if (b.count) {
-            slot_of[i] = n_slots;
-            n_slots += 1u + b.count;
-        } else {
+        slot_of[i] = uint32_t(n_slots64);
+        if (b.count)
+            n_slots64 += 1u + b.count;
+        else
             parent[b.first] = parent[b.first + 1] = i;
-        }
     }
-    if (n_slots > kLeafFirstMask) return fail(PT_ERR_LIMIT, "triangles + leaves exceed 2^27-1 leaf-array records");
+    if (n_slots64 > kLeafFirstMask) return fail(PT_ERR_LIMIT, "triangles + leaves exceed 2^27-1 leaf-array records");
+    slot_of[d->n_nodes] = uint32_t(n_slots64);
+    clk.lap("leaf slots");
     // reference-order nodes
-    {
-        std::vector<float4> n(2 * size_t(d->n_nodes));
-        for (uint32_t i = 0; i < d->n_nodes; ++i) {
-            const pt_bvh_node& b = d->nodes[i];
-            uint32_t first = b.count ? slot_of[i] + 1u : b.first, count = b.count;
-            float ff, fc;
-            std::memcpy(&ff, &first, 4);
-            std::memcpy(&fc, &count, 4);
-            n[2 * size_t(i)] = make_float4(b.lo[0], b.lo[1], b.lo[2], b.hi[0]);
-            n[2 * size_t(i) + 1] = make_float4(b.hi[1], b.hi[2], ff, fc);
-        }
-        if (int rc = upload(s, n.data(), n.size(), &dev.nodes)) return rc;
-    }
-    {
-        std::vector<float4> t(3 * size_t(n_slots));
-        for (uint32_t i = 0; i < d->n_nodes; ++i) {
-            const pt_bvh_node& b = d->nodes[i];
-            if (!b.count) continue;
-            float4* h = &t[3 * size_t(slot_of[i])];
-            const uint32_t flags = (i == 0) ? kLeafUntested : 0u;
-            float ffl;
-            std::memcpy(&ffl, &flags, 4);
-            const pt_bvh_node& pb = d->nodes[parent[i]];
-            h[0] = make_float4(pb.lo[0], pb.lo[1], pb.lo[2], pb.hi[0]);
-            h[1] = make_float4(pb.hi[1], pb.hi[2], ffl, 0.0f);
-            h[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            for (uint32_t k = 0; k < b.count; ++k) {
-                const uint32_t prim = d->prim_ids[b.first + k];
-                const float* p0 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 0] - 1);
-                const float* p1 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 1] - 1);
-                const float* p2 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 2] - 1);
-                float fp;
-                std::memcpy(&fp, &prim, 4);
-                float4* o = h + 3 * size_t(1u + k);
-                o[0] = make_float4(p0[0], p0[1], p0[2], fp);
-                o[1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.0f);
-                o[2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f);
-            }
-        }
-        if (int rc = upload(s, t.data(), t.size(), &dev.tris)) return rc;
-    }
+    if (int rc = fill_upload<float4>(
+            s, d->n_nodes, [](size_t u) { return 2 * u; }, &dev.nodes, [&](size_t i, float4* o) {
+                const pt_bvh_node& b = d->nodes[i];
+                uint32_t first = b.count ? slot_of[i] + 1u : b.first, count = b.count;
+                float ff, fc;
+                std::memcpy(&ff, &first, 4);
+                std::memcpy(&fc, &count, 4);
+                o[0] = make_float4(b.lo[0], b.lo[1], b.lo[2], b.hi[0]);
+                o[1] = make_float4(b.hi[1], b.hi[2], ff, fc);
+            }))
+        return rc;
+    // leaf array: unit = node (interior nodes contribute nothing)
+    if (int rc = fill_upload<float4>(
+            s, d->n_nodes, [&](size_t u) { return 3 * size_t(slot_of[u]); }, &dev.tris, [&](size_t i, float4* h) {
+                const pt_bvh_node& b = d->nodes[i];
+                if (!b.count) return;
+                const uint32_t flags = (i == 0) ? kLeafUntested : 0u;
+                float ffl;
+                std::memcpy(&ffl, &flags, 4);
+                const pt_bvh_node& pb = d->nodes[parent[i]];
+                h[0] = make_float4(pb.lo[0], pb.lo[1], pb.lo[2], pb.hi[0]);
+                h[1] = make_float4(pb.hi[1], pb.hi[2], ffl, 0.0f);
+                h[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (uint32_t k = 0; k < b.count; ++k) {
+                    const uint32_t prim = d->prim_ids[b.first + k];
+                    const float* p0 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 0] - 1);
+                    const float* p1 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 1] - 1);
+                    const float* p2 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 2] - 1);
+                    float fp;
+                    std::memcpy(&fp, &prim, 4);
+                    float4* o = h + 3 * size_t(1u + k);
+                    o[0] = make_float4(p0[0], p0[1], p0[2], fp);
+                    o[1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.0f);
+                    o[2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f);
+                }
+            }))
+        return rc;
+    clk.lap("binary nodes + leaf array");
     // navigation nodes of the ordered traversal: 4-wide, 64 bytes each, slot boxes on a 16-bit grid over the root box,
     // rounded outwards (box_cheap in traverse.h)
     {
@@ -316,60 +404,84 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             return uint32_t(std::min(65535.0, std::max(0.0, g)));
         };
         // Collapse: the navigation node of binary interior node N has one slot per grandchild of N, or per child where
-        // that child is a leaf.  Nodes are numbered in depth-first order from the root (a subtree is contiguous).
+        // that child is a leaf; navigation nodes are the interior nodes at even depth.  They are numbered in the order of
+        // their binary node index (the reference's numbering keeps a subtree contiguous) when every child index exceeds
+        // its parent's, as in every tree a top-down builder emits -- one streaming pass; otherwise depth-first.
         std::vector<uint32_t> wide_id(d->n_nodes, kEmptyRef), order;
         {
-            std::vector<uint32_t> stack;
-            if (d->nodes[0].count == 0) stack.push_back(0u);
-            while (!stack.empty()) {
-                const uint32_t n = stack.back();
-                stack.pop_back();
-                wide_id[n] = uint32_t(order.size());
-                order.push_back(n);
-                uint32_t slots[kWide];
-                int ns = 0;
-                for (uint32_t k = 0; k < 2; ++k) {
-                    const uint32_t c = d->nodes[n].first + k;
-                    if (d->nodes[c].count) {
-                        slots[ns++] = c;
-                    } else {
-                        slots[ns++] = d->nodes[c].first;
-                        slots[ns++] = d->nodes[c].first + 1;
-                    }
+            std::vector<uint8_t> odd(d->n_nodes, 0);  // depth parity
+            bool forward = true;
+            for (uint32_t i = 0; i < d->n_nodes && forward; ++i) {
+                const pt_bvh_node& b = d->nodes[i];
+                if (b.count) continue;
+                if (b.first <= i) {
+                    forward = false;
+                    break;
                 }
-                for (int k = ns - 1; k >= 0; --k)
-                    if (d->nodes[slots[k]].count == 0) stack.push_back(slots[k]);
+                odd[b.first] = odd[b.first + 1] = odd[i] ^ 1;
+                if (!odd[i]) {
+                    wide_id[i] = uint32_t(order.size());
+                    order.push_back(i);
+                }
+            }
+            if (!forward) {
+                std::fill(wide_id.begin(), wide_id.end(), kEmptyRef);
+                order.clear();
+                std::vector<uint32_t> stack;
+                if (d->nodes[0].count == 0) stack.push_back(0u);
+                while (!stack.empty()) {
+                    const uint32_t n = stack.back();
+                    stack.pop_back();
+                    wide_id[n] = uint32_t(order.size());
+                    order.push_back(n);
+                    uint32_t slots[kWide];
+                    int ns = 0;
+                    for (uint32_t k = 0; k < 2; ++k) {
+                        const uint32_t c = d->nodes[n].first + k;
+                        if (d->nodes[c].count) {
+                            slots[ns++] = c;
+                        } else {
+                            slots[ns++] = d->nodes[c].first;
+                            slots[ns++] = d->nodes[c].first + 1;
+                        }
+                    }
+                    for (int k = ns - 1; k >= 0; --k)
+                        if (d->nodes[slots[k]].count == 0) stack.push_back(slots[k]);
+                }
             }
         }
         auto ref_of = [&](uint32_t ni) -> uint32_t {
             const pt_bvh_node& b = d->nodes[ni];
             return b.count ? (kLeafBit | (b.count << kLeafCountShift) | slot_of[ni]) : wide_id[ni];
         };
-        std::vector<uint4> w(size_t(kWide) * std::max<size_t>(order.size(), 1), make_uint4(0u, 0u, 0u, kEmptyRef));
-        for (size_t wi = 0; wi < order.size(); ++wi) {
-            const uint32_t n = order[wi];
-            int ns = 0;
-            auto put = [&](uint32_t ci) {
-                const pt_bvh_node& c = d->nodes[ci];
-                uint4& o = w[size_t(kWide) * wi + ns++];
-                o.x = q_lo(c.lo[0], 0) | (q_hi(c.hi[0], 0) << 16);
-                o.y = q_lo(c.lo[1], 1) | (q_hi(c.hi[1], 1) << 16);
-                o.z = q_lo(c.lo[2], 2) | (q_hi(c.hi[2], 2) << 16);
-                o.w = ref_of(ci);
-            };
-            for (uint32_t k = 0; k < 2; ++k) {
-                const uint32_t c = d->nodes[n].first + k;
-                if (d->nodes[c].count) {
-                    put(c);
-                } else {
-                    put(d->nodes[c].first);
-                    put(d->nodes[c].first + 1);
-                }
-            }
-        }
+        if (int rc = fill_upload<uint4>(
+                s, std::max<size_t>(order.size(), 1), [](size_t u) { return size_t(kWide) * u; }, &dev.qnodes, [&](size_t wi, uint4* w) {
+                    for (int k = 0; k < kWide; ++k) w[k] = make_uint4(0u, 0u, 0u, kEmptyRef);
+                    if (wi >= order.size()) return;  // a scene whose root is a leaf has no navigation node
+                    const uint32_t n = order[wi];
+                    int ns = 0;
+                    auto put = [&](uint32_t ci) {
+                        const pt_bvh_node& c = d->nodes[ci];
+                        uint4& o = w[ns++];
+                        o.x = q_lo(c.lo[0], 0) | (q_hi(c.hi[0], 0) << 16);
+                        o.y = q_lo(c.lo[1], 1) | (q_hi(c.hi[1], 1) << 16);
+                        o.z = q_lo(c.lo[2], 2) | (q_hi(c.hi[2], 2) << 16);
+                        o.w = ref_of(ci);
+                    };
+                    for (uint32_t k = 0; k < 2; ++k) {
+                        const uint32_t c = d->nodes[n].first + k;
+                        if (d->nodes[c].count) {
+                            put(c);
+                        } else {
+                            put(d->nodes[c].first);
+                            put(d->nodes[c].first + 1);
+                        }
+                    }
+                }))
+            return rc;
         dev.wide_root = ref_of(0);
-        if (int rc = upload(s, w.data(), w.size(), &dev.qnodes)) return rc;
     }
+    clk.lap("navigation nodes");
     // shading records: one 128-byte record per triangle, one 96-byte record per light
     {
         auto vert = [&](uint32_t prim, int k) { return d->verts + 3 * size_t(d->vi[3 * size_t(prim) + k] - 1); };
@@ -395,25 +507,25 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             o[3] = make_float4(n[3], n[4], n[5], n[6]);
             o[4] = make_float4(n[7], n[8], 0.0f, 0.0f);
         };
-        std::vector<float4> trec(size_t(kTriRecVec4) * d->n_tris);
-        for (uint32_t t = 0; t < d->n_tris; ++t) {
-            float4* o = &trec[size_t(kTriRecVec4) * t];
-            pack_geometry(t, o);
-            uint32_t flags = has_normals(t) ? kTriHasNormals : 0u;
-            if (d->n_uvs != 0 && d->ti && d->ti[3 * size_t(t)] != 0) flags |= kTriHasUvs;
-            const int32_t lid = d->light_id[t];
-            o[4].z = bits(flags);
-            o[4].w = bits(uint32_t(lid));
-            const pt_material& m = d->mats[d->mat_id[t]];
-            o[5] = make_float4(m.kd[0], m.kd[1], m.kd[2], m.ns);
-            o[6] = make_float4(m.ks[0], m.ks[1], m.ks[2], bits(uint32_t(m.tex)));
-            o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (lid >= 0) {
-                const pt_light& l = d->lights[lid];
-                o[7] = make_float4(l.lemit[0], l.lemit[1], l.lemit[2], float(1.0 / double(l.area)));
-            }
-        }
-        if (int rc = upload(s, trec.data(), trec.size(), &dev.trec)) return rc;
+        if (int rc = fill_upload<float4>(
+                s, d->n_tris, [](size_t u) { return size_t(kTriRecVec4) * u; }, &dev.trec, [&](size_t ti_, float4* o) {
+                    const uint32_t t = uint32_t(ti_);
+                    pack_geometry(t, o);
+                    uint32_t flags = has_normals(t) ? kTriHasNormals : 0u;
+                    if (d->n_uvs != 0 && d->ti && d->ti[3 * size_t(t)] != 0) flags |= kTriHasUvs;
+                    const int32_t lid = d->light_id[t];
+                    o[4].z = bits(flags);
+                    o[4].w = bits(uint32_t(lid));
+                    const pt_material& m = d->mats[d->mat_id[t]];
+                    o[5] = make_float4(m.kd[0], m.kd[1], m.kd[2], m.ns);
+                    o[6] = make_float4(m.ks[0], m.ks[1], m.ks[2], bits(uint32_t(m.tex)));
+                    o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (lid >= 0) {
+                        const pt_light& l = d->lights[lid];
+                        o[7] = make_float4(l.lemit[0], l.lemit[1], l.lemit[2], float(1.0 / double(l.area)));
+                    }
+                }))
+            return rc;
         std::vector<float4> lrec(size_t(kLightRecVec4) * d->n_lights);
         for (uint32_t i = 0; i < d->n_lights; ++i) {
             const pt_light& l = d->lights[i];
@@ -437,6 +549,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
         if (int rc = upload(s, t.data(), t.size(), &dev.textures)) return rc;
         if (int rc = upload(s, texels.data(), texels.size(), &dev.tex_data)) return rc;
     }
+    clk.lap("shading records + textures");
     dev.n_tris = d->n_tris;
     dev.n_lights = d->n_lights;
     {
@@ -941,7 +1054,27 @@ int pt_hip_scene_create(const pt_scene_desc* desc, pt_hip_scene** out) {
     if (g_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
     if (!out) return fail(PT_ERR_INVALID, "output handle pointer is null");
     uint32_t depth = 0;
+    PhaseClock clk;
+    // a description without a tree: build the reference's tree here, on the GPU
+    pt_scene_desc with_tree;
+    struct Built {
+        pt_bvh_node* nodes = nullptr;
+        uint32_t* ids = nullptr;
+        ~Built() {
+            pt_hip_free(nodes);
+            pt_hip_free(ids);
+        }
+    } built;
+    if (desc && desc->n_nodes == 0 && !desc->nodes && !desc->prim_ids && desc->verts && desc->vi && desc->n_tris) {
+        with_tree = *desc;
+        if (int rc = pt_hip_build_bvh(desc->verts, desc->n_verts, desc->vi, desc->n_tris, &built.nodes, &with_tree.n_nodes, &built.ids, nullptr)) return rc;
+        with_tree.nodes = built.nodes;
+        with_tree.prim_ids = built.ids;
+        desc = &with_tree;
+        clk.lap("tree (pt_hip_build_bvh)");
+    }
     if (int rc = validate(desc, depth)) return rc;
+    clk.lap("validate");
     pt_hip_scene* s = new pt_hip_scene();
     s->depth = depth;
     if (int rc = build_scene(s, desc)) {

@@ -205,9 +205,11 @@ def filter_table():
 class HostScene:
     """A pt_scene_desc assembled from a SceneData through the host substrate (BVH, camera, light table)."""
 
-    def __init__(self, sd, bvh=None):
+    def __init__(self, sd, bvh=None, builder="host"):
         """bvh = (nodes as NODE_DTYPE, prim_ids): use this tree instead of building the reference's (any binary tree in
-        the reference's node layout is a valid input of the backend; tests use it for shapes the builder never makes)."""
+        the reference's node layout is a valid input of the backend; tests use it for shapes the builder never makes).
+        builder: "host" = pt_host_build_bvh, "gpu" = pt_hip_build_bvh (the same tree, built on the device),
+        "deferred" = leave the tree out of the description: pt_hip_scene_create builds it."""
         self.sd = sd
         k = self.keep = {}
         k["verts"] = np.ascontiguousarray(sd.verts, np.float32)
@@ -219,8 +221,10 @@ class HostScene:
         mats["kd"], mats["ks"], mats["ns"], mats["tex"] = sd.mat_kd, sd.mat_ks, sd.mat_ns, sd.mat_tex
         k["mats"] = mats
         k["lights"], k["light_id"] = make_lights(sd)
-        if bvh is None:
-            self.nodes, self.prim_ids, self.depth = build_bvh(k["verts"], k["vi"])
+        if bvh is None and builder == "deferred":
+            self.nodes, self.prim_ids, self.depth = np.zeros(0, NODE_DTYPE), np.zeros(0, np.uint32), None
+        elif bvh is None:
+            self.nodes, self.prim_ids, self.depth = (build_bvh_gpu if builder == "gpu" else build_bvh)(k["verts"], k["vi"])
         else:
             self.nodes, self.prim_ids, self.depth = np.ascontiguousarray(bvh[0], NODE_DTYPE), np.ascontiguousarray(bvh[1], np.uint32), None
         k["tex"] = [np.ascontiguousarray(t, np.float32) for t in sd.textures]
@@ -238,8 +242,9 @@ class HostScene:
         d.lights = k["lights"].ctypes.data_as(C.POINTER(Light))
         d.textures = C.cast(texs, C.POINTER(Texture))
         d.camera = make_camera(sd)
-        d.nodes = self.nodes.ctypes.data_as(C.POINTER(BvhNode))
-        d.prim_ids = _p(self.prim_ids, c_u32p)
+        if len(self.nodes):
+            d.nodes = self.nodes.ctypes.data_as(C.POINTER(BvhNode))
+            d.prim_ids = _p(self.prim_ids, c_u32p)
 
 
 # ------------------------------------------------------------------------------------------------- device backend
@@ -257,9 +262,10 @@ def init(device=0):
 class Scene:
     """Device scene (pt_hip_scene) built from a SceneData."""
 
-    def __init__(self, sd, device=0, bvh=None):
+    def __init__(self, sd, device=0, bvh=None, builder="gpu"):
+        """builder: who builds the reference-topology tree when bvh is None (see HostScene); the GPU builder by default."""
         init(device)
-        self.host = HostScene(sd, bvh)
+        self.host = HostScene(sd, bvh, builder)
         self.sd = sd
         h = C.c_void_p()
         _chk(hip_lib().pt_hip_scene_create(C.byref(self.host.desc), C.byref(h)))

@@ -629,3 +629,22 @@ def test_gpu_tree_build_equals_the_host_builder_node_for_node(make, veach_sd):
     assert len(nodes) == len(want_nodes) and depth == want_depth
     assert np.array_equal(ids, want_ids)
     assert np.array_equal(nodes.view(np.uint32), want_nodes.view(np.uint32))
+
+
+def test_scene_description_without_a_tree_is_built_on_the_device():
+    """pt_hip_scene_create with nodes == NULL builds the reference's tree itself: same hits, same film as with the host
+    builder's tree handed over."""
+    sd = synth.library_synth(detail=1)
+    a, b = api.Scene(sd, builder="host"), api.Scene(sd, builder="deferred")
+    assert len(b.host.nodes) == 0
+    o = orc.Scene(sd)
+    rays = helpers.primary_rays(o, sample=0, step=8)
+    for mode in (api.TRAVERSE_EXACT, api.TRAVERSE_FAST):
+        ha, hb = a.intersect(rays, mode), b.intersect(rays, mode)
+        assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32))
+    assert helpers.hits_equal(hb, o.intersect(rays)).all()
+    fa, sa = a.render(0, 2, traversal=api.TRAVERSE_FAST)
+    fb, sb = b.render(0, 2, traversal=api.TRAVERSE_FAST)
+    assert (sa["closest_rays"], sa["any_rays"]) == (sb["closest_rays"], sb["any_rays"]) and np.allclose(fa, fb, rtol=1e-5, atol=1e-6)
+    a.close()
+    b.close()
