@@ -6,10 +6,13 @@
  * Every function returns 0 on success and a negative pt_status on failure; pt_hip_last_error() gives the message
  * (thread-local), which a C++ host rethrows as the reference's PathTracerException (include/pt/common.h:75-80).
  *
- * One process drives one GPU (pt_hip_init selects it); multi-GPU rendering is N processes that each render a
- * disjoint sample range into their own film and sum the films with one reduce.
+ * Multi-GPU rendering splits one frame by sample number (or by 32x32 pixel blocks) and sums the films with one
+ * reduction.  Two hosts for that: one process per GPU (pt_hip_init selects the GPU, the films are reduced by the caller,
+ * e.g. with RCCL), or one process driving several GPUs: a scene handle is bound to the GPU it was created on
+ * (pt_hip_scene_create_on) and owns a stream there, and pt_hip_render_multi renders one frame on a set of handles.
  *
- * The handle is not thread-safe: call from one host thread, as the reference's render thread does (src/main.cpp:185).
+ * A handle is not thread-safe: one host thread per handle at a time, as the reference's render thread
+ * (src/main.cpp:185); different handles may be driven from different threads concurrently.
  *
  * File:line citations are relative to the reference repository root.
  */
@@ -171,7 +174,8 @@ typedef struct pt_hip_scene pt_hip_scene;
 
 /* ---- life cycle --------------------------------------------------------------------------------------------------- */
 
-/* Selects the GPU this process drives and creates its stream.  No counterpart in the reference (CPU only). */
+/* Selects the default GPU of this process (the one pt_hip_scene_create and the entry points without a handle use) and
+ * creates its stream.  No counterpart in the reference (CPU only). */
 int pt_hip_init(int device_ordinal);
 /* Number of GPUs visible to this process (>= 0), or a negative PT_ERR_*.  May be called before pt_hip_init. */
 int pt_hip_device_count(void);
@@ -183,6 +187,9 @@ int pt_hip_abi_version(void);
  * (src/scene.cpp:231-232): validates the description, flattens the host-built BVH into the device layouts and
  * uploads mesh, materials, lights, camera and the Sobol' tables. */
 int pt_hip_scene_create(const pt_scene_desc* desc, pt_hip_scene** out);
+/* The same on an explicit GPU (0 <= device_ordinal < pt_hip_device_count()): the handle, its device copies and its stream
+ * live there, whichever GPU pt_hip_init selected. */
+int pt_hip_scene_create_on(int device_ordinal, const pt_scene_desc* desc, pt_hip_scene** out);
 /* Replaces `delete m_accel` in Scene::~Scene (include/pt/scene.h:18-26): frees device copies only. */
 int pt_hip_scene_destroy(pt_hip_scene* scene);
 
@@ -228,6 +235,13 @@ int pt_hip_intersect_device_noalloc(pt_hip_scene* scene, const pt_ray* d_rays, s
 int pt_hip_render(pt_hip_scene* scene, const pt_render_params* params, float* film_rgba, pt_stats* stats);
 /* Same with the film in device memory (for a device-side reduce across processes). */
 int pt_hip_render_device(pt_hip_scene* scene, const pt_render_params* params, float* d_film_rgba, pt_stats* stats);
+
+/* render(...) (src/main.cpp:76-98) of one frame on n handles of the same scene, one per GPU, from one process: the sample
+ * range [spp_begin, spp_end) is cut into n contiguous shares (or, with block_count == n, handle k renders the 32x32
+ * blocks of rank k), one host thread drives each handle, and the films are summed on the first handle's GPU (peer copies
+ * over xGMI + one add per film: the frame's only reduction, src/block.cpp:102-110) and copied to film_rgba (host).
+ * stats: counts and per-kernel times summed over the GPUs, seconds = wall time of the call. */
+int pt_hip_render_multi(pt_hip_scene* const* scenes, int n, const pt_render_params* params, float* film_rgba, pt_stats* stats);
 
 /* Integrator::Li (include/pt/integrator.h:9-19) for an explicit list of (pixel, sample index) pairs: writes the
  * radiance of each sample (3 floats) and its film position (2 floats, nullable) without touching a film.

@@ -315,12 +315,8 @@ struct KeyIdx {
 
 }  // namespace
 
-extern "C" {
-
-void pt_hip_free(void* p) { std::free(p); }
-
-int pt_hip_build_bvh(const float* verts, uint32_t n_verts, const uint32_t* vi, uint32_t n_tris, pt_bvh_node** nodes_out, uint32_t* n_nodes_out,
-                     uint32_t** prim_ids_out, uint32_t* max_depth_out) {
+int pth::build_bvh_on_current(const float* verts, uint32_t n_verts, const uint32_t* vi, uint32_t n_tris, pt_bvh_node** nodes_out, uint32_t* n_nodes_out,
+                              uint32_t** prim_ids_out, uint32_t* max_depth_out) {
     if (pth::device() < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
     if (!verts || !vi || !nodes_out || !n_nodes_out || !prim_ids_out || n_tris == 0) return fail(PT_ERR_INVALID, "null argument or empty mesh");
     if (n_tris > 0x3fffffffu) return fail(PT_ERR_LIMIT, "too many triangles");
@@ -498,6 +494,16 @@ int pt_hip_build_bvh(const float* verts, uint32_t n_verts, const uint32_t* vi, u
                      levels, s(t0, t1), s(t1, t2), s(t2, t3));
     }
     return PT_OK;
+}
+
+extern "C" {
+
+void pt_hip_free(void* p) { std::free(p); }
+
+int pt_hip_build_bvh(const float* verts, uint32_t n_verts, const uint32_t* vi, uint32_t n_tris, pt_bvh_node** nodes, uint32_t* n_nodes, uint32_t** prim_ids,
+                     uint32_t* max_depth) {
+    if (int rc = pth::bind_default()) return rc;
+    return pth::build_bvh_on_current(verts, n_verts, vi, n_tris, nodes, n_nodes, prim_ids, max_depth);
 }
 
 }  // extern "C"

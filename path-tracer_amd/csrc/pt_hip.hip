@@ -26,8 +26,14 @@ using namespace ptd;
 namespace {
 
 thread_local std::string g_error;
-int g_device = -1;
-hipStream_t g_stream = nullptr;
+// The device and stream the calling thread works on.  A scene handle is bound to the device it was created on and owns a
+// stream there; every entry point that takes a handle makes that pair the thread's current one (bind), so several
+// handles -- one per GPU -- can be driven from several host threads of one process.  Entry points without a handle use
+// the pair pt_hip_init set up.
+int g_default_device = -1;
+hipStream_t g_default_stream = nullptr;
+thread_local int g_device = -1;
+thread_local hipStream_t g_stream = nullptr;
 
 constexpr uint32_t kMaxGridY = 65535;
 constexpr uint32_t kMaxGridZ = 8;  // shards of a pass: up to kMaxGridZ * kMaxGridY (2^31 slots would be 524288 shards)
@@ -153,6 +159,8 @@ struct pt_hip_scene {
     uint32_t width = 0, height = 0;
     Workspace ws;
     EventPool events;
+    int device = -1;                  // the GPU this handle lives on
+    hipStream_t stream = nullptr;     // its own stream there
     uint32_t* batch_fetch = nullptr;  // per-shard fetch counters of the batched ordered queries
     size_t batch_fetch_cap = 0;
     // grow-only device staging of the host-pointer entry points (rays, hits, flags, sample lists, film), so that a
@@ -885,9 +893,32 @@ int stage_reserve(pt_hip_scene* s, int slot, size_t bytes, T** out) {
     return PT_OK;
 }
 
+// makes pt_hip_init's device and stream the calling thread's current pair
+int bind_default() {
+    if (g_default_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
+    HIP_TRY(hipSetDevice(g_default_device));
+    g_device = g_default_device;
+    g_stream = g_default_stream;
+    return PT_OK;
+}
+
+// this device's copy of the static fetch counters (pt_hip_intersect_device_noalloc); the device must be current
+int noalloc_address(int device) {
+    if (device < kMaxDevices && !g_noalloc_fetch[device]) {
+        uint32_t* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch)));
+        g_noalloc_fetch[device] = p;
+    }
+    return PT_OK;
+}
+
+// every entry point that takes a handle starts here: the handle's device and stream become the thread's current pair
 int check_ready(const pt_hip_scene* s) {
-    if (g_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
+    if (g_default_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
     if (!s) return fail(PT_ERR_INVALID, "scene handle is null");
+    HIP_TRY(hipSetDevice(s->device));
+    g_device = s->device;
+    g_stream = s->stream;
     return PT_OK;
 }
 
@@ -1003,6 +1034,7 @@ int prepare_split(pt_hip_scene* s, uint32_t rank, uint32_t count, uint32_t tiles
 
 namespace pth {
 int fail(int code, const std::string& msg) { return ::fail(code, msg); }
+int bind_default() { return ::bind_default(); }
 hipStream_t stream() { return g_stream; }
 int device() { return g_device; }
 }  // namespace pth
@@ -1026,33 +1058,57 @@ int pt_hip_init(int device_ordinal) {
     if (device_ordinal < 0 || device_ordinal >= n)
         return fail(PT_ERR_INVALID, "device ordinal " + std::to_string(device_ordinal) + " out of range (" + std::to_string(n) + " devices)");
     HIP_TRY(hipSetDevice(device_ordinal));
-    if (g_stream && g_device != device_ordinal) {
-        (void)hipStreamDestroy(g_stream);
-        g_stream = nullptr;
+    if (g_default_stream && g_default_device != device_ordinal) {
+        (void)hipStreamDestroy(g_default_stream);
+        g_default_stream = nullptr;
     }
-    if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    if (device_ordinal < kMaxDevices && !g_noalloc_fetch[device_ordinal]) {  // this device's copy of the static fetch counters
-        uint32_t* p = nullptr;
-        HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch)));
-        g_noalloc_fetch[device_ordinal] = p;
-    }
-    g_device = device_ordinal;
-    return PT_OK;
+    if (!g_default_stream) HIP_TRY(hipStreamCreateWithFlags(&g_default_stream, hipStreamNonBlocking));
+    if (int rc = noalloc_address(device_ordinal)) return rc;
+    g_default_device = device_ordinal;
+    return bind_default();
 }
 
 int pt_hip_shutdown(void) {
-    if (g_stream) {
-        (void)hipStreamSynchronize(g_stream);
-        (void)hipStreamDestroy(g_stream);
-        g_stream = nullptr;
+    if (g_default_stream) {
+        (void)hipSetDevice(g_default_device);
+        (void)hipStreamSynchronize(g_default_stream);
+        (void)hipStreamDestroy(g_default_stream);
+        g_default_stream = nullptr;
     }
+    g_default_device = -1;
     g_device = -1;
+    g_stream = nullptr;
     return PT_OK;
 }
 
 int pt_hip_scene_create(const pt_scene_desc* desc, pt_hip_scene** out) {
-    if (g_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
+    if (g_default_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
+    return pt_hip_scene_create_on(g_default_device, desc, out);
+}
+
+int pt_hip_scene_create_on(int device_ordinal, const pt_scene_desc* desc, pt_hip_scene** out) {
+    if (g_default_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
     if (!out) return fail(PT_ERR_INVALID, "output handle pointer is null");
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device_ordinal < 0 || device_ordinal >= n_dev)
+        return fail(PT_ERR_INVALID, "device ordinal " + std::to_string(device_ordinal) + " out of range (" + std::to_string(n_dev) + " devices)");
+    // the handle's stream first: everything below (tree build, uploads) already runs on it
+    HIP_TRY(hipSetDevice(device_ordinal));
+    hipStream_t stream = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    struct StreamGuard {  // on every failure below: no stream left behind, and the thread's current pair does not dangle
+        hipStream_t st;
+        ~StreamGuard() {
+            if (!st) return;
+            (void)hipStreamDestroy(st);
+            g_stream = nullptr;
+            g_device = -1;
+        }
+    } guard{stream};
+    if (int rc = noalloc_address(device_ordinal)) return rc;
+    g_device = device_ordinal;
+    g_stream = stream;
     uint32_t depth = 0;
     PhaseClock clk;
     // a description without a tree: build the reference's tree here, on the GPU
@@ -1067,7 +1123,8 @@ int pt_hip_scene_create(const pt_scene_desc* desc, pt_hip_scene** out) {
     } built;
     if (desc && desc->n_nodes == 0 && !desc->nodes && !desc->prim_ids && desc->verts && desc->vi && desc->n_tris) {
         with_tree = *desc;
-        if (int rc = pt_hip_build_bvh(desc->verts, desc->n_verts, desc->vi, desc->n_tris, &built.nodes, &with_tree.n_nodes, &built.ids, nullptr)) return rc;
+        if (int rc = pth::build_bvh_on_current(desc->verts, desc->n_verts, desc->vi, desc->n_tris, &built.nodes, &with_tree.n_nodes, &built.ids, nullptr))
+            return rc;
         with_tree.nodes = built.nodes;
         with_tree.prim_ids = built.ids;
         desc = &with_tree;
@@ -1077,6 +1134,9 @@ int pt_hip_scene_create(const pt_scene_desc* desc, pt_hip_scene** out) {
     clk.lap("validate");
     pt_hip_scene* s = new pt_hip_scene();
     s->depth = depth;
+    s->device = device_ordinal;
+    s->stream = stream;
+    guard.st = nullptr;  // the handle owns it now
     if (int rc = build_scene(s, desc)) {
         pt_hip_scene_destroy(s);
         return rc;
@@ -1087,7 +1147,8 @@ int pt_hip_scene_create(const pt_scene_desc* desc, pt_hip_scene** out) {
 
 int pt_hip_scene_destroy(pt_hip_scene* s) {
     if (!s) return PT_OK;
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    if (s->device >= 0) (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
     ws_release(s->ws);
     for (hipEvent_t e : s->events.ev) (void)hipEventDestroy(e);
     if (s->batch_fetch) (void)hipFree(s->batch_fetch);
@@ -1096,6 +1157,11 @@ int pt_hip_scene_destroy(pt_hip_scene* s) {
     for (hipEvent_t e : s->query_ev)
         if (e) (void)hipEventDestroy(e);
     for (void* p : s->owned) (void)hipFree(p);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (g_stream == s->stream) {  // the thread's current pair must not dangle
+        g_stream = nullptr;
+        g_device = -1;
+    }
     delete s;
     return PT_OK;
 }
@@ -1301,6 +1367,95 @@ int pt_hip_render(pt_hip_scene* s, const pt_render_params* params, float* film, 
     return PT_OK;
 }
 
+// adds b to a (n floats)
+__global__ void k_add_film(float* a, const float* b, size_t n) {
+    const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+
+int pt_hip_render_multi(pt_hip_scene* const* scenes, int n, const pt_render_params* params, float* film, pt_stats* st) {
+    if (!scenes || n <= 0) return fail(PT_ERR_INVALID, "no scene handles");
+    if (!film) return fail(PT_ERR_INVALID, "film pointer is null");
+    pt_render_params p;
+    if (int rc = normalise(params, p)) return rc;
+    for (int k = 0; k < n; ++k) {
+        if (!scenes[k]) return fail(PT_ERR_INVALID, "scene handle is null");
+        if (scenes[k]->width != scenes[0]->width || scenes[k]->height != scenes[0]->height) return fail(PT_ERR_INVALID, "handles of different image sizes");
+        for (int j = 0; j < k; ++j)
+            if (scenes[j] == scenes[k]) return fail(PT_ERR_INVALID, "the same handle twice");
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t floats = 4 * size_t(scenes[0]->width + 4) * size_t(scenes[0]->height + 4), bytes = floats * sizeof(float);
+    // shares: contiguous ranges of sample numbers, or the 32x32 blocks of one rank each when the caller asked for blocks
+    const bool by_blocks = p.block_count > 1;
+    if (by_blocks && int(p.block_count) != n) return fail(PT_ERR_INVALID, "block_count must equal the number of handles");
+    const uint32_t total = p.spp_end - p.spp_begin;
+    std::vector<pt_render_params> share(n, p);
+    std::vector<float*> d_film(n, nullptr);
+    std::vector<pt_stats> stats(n);
+    std::vector<int> rcs(n, PT_OK);
+    std::vector<std::string> errs(n);
+    for (int k = 0; k < n; ++k) {
+        if (by_blocks) {
+            share[k].block_rank = uint16_t(k);
+        } else {
+            const uint32_t base = total / uint32_t(n), rem = total % uint32_t(n);
+            share[k].spp_begin = p.spp_begin + uint32_t(k) * base + std::min(uint32_t(k), rem);
+            share[k].spp_end = share[k].spp_begin + base + (uint32_t(k) < rem ? 1u : 0u);
+        }
+        if (int rc = check_ready(scenes[k])) return rc;
+        if (int rc = stage_reserve(scenes[k], 3, bytes, &d_film[k])) return rc;
+    }
+    // one host thread per handle, as the single-GPU entry point is driven
+    std::vector<std::thread> th;
+    for (int k = 0; k < n; ++k)
+        th.emplace_back([&, k] {
+            if (share[k].spp_end <= share[k].spp_begin) {  // more GPUs than samples: an empty film
+                rcs[k] = check_ready(scenes[k]);
+                if (!rcs[k] && (hipMemsetAsync(d_film[k], 0, bytes, g_stream) != hipSuccess || hipStreamSynchronize(g_stream) != hipSuccess))
+                    rcs[k] = PT_ERR_DEVICE;
+                std::memset(&stats[k], 0, sizeof(pt_stats));
+            } else {
+                rcs[k] = pt_hip_render_device(scenes[k], &share[k], d_film[k], &stats[k]);
+            }
+            if (rcs[k]) errs[k] = g_error;
+        });
+    for (std::thread& t : th) t.join();
+    for (int k = 0; k < n; ++k)
+        if (rcs[k]) return fail(rcs[k], "GPU " + std::to_string(scenes[k]->device) + ": " + errs[k]);
+    // the one reduction of the frame (src/block.cpp:102-110): films are summed on the first handle's GPU
+    if (int rc = check_ready(scenes[0])) return rc;
+    float* d_tmp = nullptr;
+    if (n > 1)
+        if (int rc = stage_reserve(scenes[0], 4, bytes, &d_tmp)) return rc;
+    for (int k = 1; k < n; ++k) {
+        HIP_TRY(hipMemcpyPeerAsync(d_tmp, scenes[0]->device, d_film[k], scenes[k]->device, bytes, g_stream));
+        hipLaunchKernelGGL(k_add_film, dim3(unsigned((floats + 255) / 256)), dim3(256), 0, g_stream, d_film[0], d_tmp, floats);
+    }
+    HIP_TRY(hipMemcpyAsync(film, d_film[0], bytes, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipGetLastError());
+    if (st) {
+        std::memset(st, 0, sizeof(*st));
+        for (int k = 0; k < n; ++k) {
+            st->paths += stats[k].paths;
+            st->closest_rays += stats[k].closest_rays;
+            st->any_rays += stats[k].any_rays;
+            st->exact_retraces += stats[k].exact_retraces;
+            for (int j = 0; j < 3; ++j) {
+                st->nodes_fetched[j] += stats[k].nodes_fetched[j];
+                st->tris_fetched[j] += stats[k].tris_fetched[j];
+            }
+            for (int j = 0; j < PT_MAX_KERNEL_STATS; ++j) {
+                st->kernel_ms[j] += stats[k].kernel_ms[j];
+                st->kernel_launches[j] += stats[k].kernel_launches[j];
+            }
+        }
+        st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return PT_OK;
+}
+
 int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pixel_xy, const uint32_t* sample_index, size_t n, float* rgb,
               float* pixel_sample, pt_stats* st) {
     if (int rc = check_ready(s)) return rc;
@@ -1378,7 +1533,7 @@ int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pi
 }
 
 int pt_hip_selftest_division(uint64_t pairs, uint64_t seed, uint64_t* mismatches) {
-    if (g_device < 0) return fail(PT_ERR_NOT_INIT, "pt_hip_init has not been called");
+    if (int rc = bind_default()) return rc;
     if (!mismatches) return fail(PT_ERR_INVALID, "null output");
     unsigned long long* d = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long)));

@@ -72,13 +72,14 @@ private:
 // (one launch per call: use the batched forms for anything but debugging).
 class Accel {
 public:
-    Accel(const Scene* scene, int traversal = PT_TRAVERSE_FAST) : m_host(scene), m_traversal(traversal) {}
+    // device < 0: the GPU pt_hip_init selected; otherwise the handle is bound to that GPU (several per process are fine)
+    Accel(const Scene* scene, int traversal = PT_TRAVERSE_FAST, int device = -1) : m_host(scene), m_traversal(traversal), m_device(device) {}
     ~Accel() { pt_hip_scene_destroy(m_dev); }
     Accel(const Accel&) = delete;
     Accel& operator=(const Accel&) = delete;
 
     void build() {
-        if (!m_dev) check(pt_hip_scene_create(m_host->desc(), &m_dev));
+        if (!m_dev) check(m_device < 0 ? pt_hip_scene_create(m_host->desc(), &m_dev) : pt_hip_scene_create_on(m_device, m_host->desc(), &m_dev));
     }
     bool rayIntersect(const Ray& ray, Intersection& its) {
         pt_hit h;
@@ -114,6 +115,7 @@ private:
     const Scene* m_host;
     pt_hip_scene* m_dev = nullptr;
     int m_traversal;
+    int m_device;
 };
 
 // The three integrators of src/integrator.cpp selected by value; Li() is not exposed per sample on purpose (the
@@ -182,6 +184,28 @@ inline pt_stats render(Accel* accel, const Integrator* integrator, uint32_t spp_
     Film part(result->width, result->height);
     pt_stats st{};
     check(pt_hip_render(accel->handle(), &p, part.rgba.data(), &st));
+    result->add(part);
+    return st;
+}
+
+// The same frame on several accelerators of one scene, one per GPU, from this process (pt_hip_render_multi): the sample
+// range is cut into contiguous shares, or with by_blocks every accelerator renders its share of the 32x32 pixel blocks;
+// the films are summed on the first one's GPU.  Adds into `result`.
+inline pt_stats render(const std::vector<Accel*>& accels, const Integrator* integrator, uint32_t spp_begin, uint32_t spp_end, Film* result,
+                       bool by_blocks = false) {
+    if (accels.size() == 1) return render(accels[0], integrator, spp_begin, spp_end, result);
+    pt_render_params p{};
+    p.spp_begin = spp_begin;
+    p.spp_end = spp_end;
+    p.max_bounce = 32;
+    p.block_count = by_blocks ? uint16_t(accels.size()) : uint16_t(0);
+    p.integrator = integrator->kind();
+    p.traversal = accels[0]->traversal();
+    std::vector<pt_hip_scene*> handles;
+    for (Accel* a : accels) handles.push_back(a->handle());
+    Film part(result->width, result->height);
+    pt_stats st{};
+    check(pt_hip_render_multi(handles.data(), int(handles.size()), &p, part.rgba.data(), &st));
     result->add(part);
     return st;
 }

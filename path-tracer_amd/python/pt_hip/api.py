@@ -109,6 +109,8 @@ def hip_lib():
         L.pt_hip_last_error.restype = C.c_char_p
         L.pt_hip_init.argtypes = [C.c_int]
         L.pt_hip_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        L.pt_hip_scene_create_on.argtypes = [C.c_int, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        L.pt_hip_render_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(RenderParams), c_f32p, C.POINTER(Stats)]
         L.pt_hip_scene_destroy.argtypes = [C.c_void_p]
         L.pt_hip_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.pt_hip_occluded.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, c_u8p, c_i32p, C.c_int]
@@ -253,8 +255,10 @@ _inited = None
 
 
 def init(device=0):
+    """pt_hip_init once per process: `device` becomes the default GPU (of pt_hip_scene_create and the calls without a
+    handle); later calls with another ordinal leave it alone -- handles are bound to their own GPU (Scene(device=...))."""
     global _inited
-    if _inited != device:
+    if _inited is None:
         _chk(hip_lib().pt_hip_init(device))
         _inited = device
 
@@ -267,8 +271,9 @@ class Scene:
         init(device)
         self.host = HostScene(sd, bvh, builder)
         self.sd = sd
+        self.device = device
         h = C.c_void_p()
-        _chk(hip_lib().pt_hip_scene_create(C.byref(self.host.desc), C.byref(h)))
+        _chk(hip_lib().pt_hip_scene_create_on(device, C.byref(self.host.desc), C.byref(h)))
         self.h = h
 
     def close(self):
@@ -346,6 +351,17 @@ class Scene:
         out = np.zeros(len(pix), np.float32)
         _chk(hip_lib().pt_hip_sobol(self.h, _p(pix, c_i32p), _p(smp, c_u32p), _p(dim, c_u32p), len(pix), _p(out, c_f32p)))
         return out
+
+
+def render_multi(scenes, spp_begin, spp_end, **kw):
+    """One frame on several handles of the same scene (one per GPU) from this process: pt_hip_render_multi."""
+    sd = scenes[0].sd
+    film = np.zeros((sd.height + 4, sd.width + 4, 4), np.float32)
+    st = Stats()
+    p = scenes[0].params(spp_begin, spp_end, **kw)
+    handles = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
+    _chk(hip_lib().pt_hip_render_multi(handles, len(scenes), C.byref(p), _p(film, c_f32p), C.byref(st)))
+    return film, st.as_dict()
 
 
 def device_count():

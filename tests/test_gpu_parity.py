@@ -648,3 +648,44 @@ def test_scene_description_without_a_tree_is_built_on_the_device():
     assert (sa["closest_rays"], sa["any_rays"]) == (sb["closest_rays"], sb["any_rays"]) and np.allclose(fa, fb, rtol=1e-5, atol=1e-6)
     a.close()
     b.close()
+
+
+# ------------------------------------------------------------------------------------------------ several handles, one process
+
+def test_one_process_drives_several_handles():
+    """pt_hip_scene_create_on + pt_hip_render_multi: three handles of one scene (on a one-GPU box they share the GPU; on a
+    node each sits on its own), one host thread per handle inside the call.  The frame split by sample number (5 samples
+    over 3 handles: shares of 2, 2, 1) and by 32x32 blocks equals the frame of a single handle; more handles than samples
+    leaves the surplus films empty; batched queries on two handles from two threads at once give the single-thread answers."""
+    import threading
+    sd = synth.cornell_box(200, 136)
+    n_dev = api.device_count()
+    g = [api.Scene(sd, device=k % n_dev) for k in range(3)]
+    whole, wst = g[0].render(0, 5, traversal=api.TRAVERSE_FAST)
+    film, st = api.render_multi(g, 0, 5, traversal=api.TRAVERSE_FAST)
+    assert st["paths"] == wst["paths"] == 200 * 136 * 5
+    assert (st["closest_rays"], st["any_rays"]) == (wst["closest_rays"], wst["any_rays"])
+    assert np.allclose(film, whole, rtol=1e-5, atol=1e-5)
+    film, st = api.render_multi(g, 0, 5, traversal=api.TRAVERSE_FAST, block=(0, 3))
+    assert st["paths"] == wst["paths"] and np.allclose(film, whole, rtol=1e-5, atol=1e-5)
+    film, st = api.render_multi(g, 3, 5, traversal=api.TRAVERSE_FAST)          # 2 samples, 3 handles
+    two, _ = g[1].render(3, 5, traversal=api.TRAVERSE_FAST)
+    assert st["paths"] == 200 * 136 * 2 and np.allclose(film, two, rtol=1e-5, atol=1e-5)
+    with pytest.raises(api.PtError, match="block_count must equal"):
+        api.render_multi(g, 0, 5, block=(0, 2))
+    o = orc.Scene(sd)
+    rays = helpers.primary_rays(o, sample=0, step=2)
+    want = g[0].intersect(rays, api.TRAVERSE_FAST)
+    got = [None, None]
+
+    def work(k):
+        for _ in range(5):
+            got[k] = g[1 + k].intersect(rays, api.TRAVERSE_FAST)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert np.array_equal(got[0].view(np.uint32), want.view(np.uint32)) and np.array_equal(got[1].view(np.uint32), want.view(np.uint32))
+    for s in g:
+        s.close()
