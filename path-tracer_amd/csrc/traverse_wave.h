@@ -4,7 +4,8 @@
 //   - lanes whose query has ended take the next ray from the queue as soon as too few lanes are left busy, instead of
 //     idling until the slowest lane of the wave is done.
 // The ordered lanes (ClosestLane, AnyLane) navigate with the conservative slab test box_cheap and take the reference's
-// exact box decision once per visited leaf, on the leaf's parent box (why that is enough: traverse.h, above box_cheap);
+// exact box decision once per query, on the parent box of the leaf that holds the result (why that is enough:
+// traverse.h, above box_cheap; why it can wait until the walk has ended: ClosestLane::leaf);
 // candidates are the triangles the reference would accept, and two candidates (or a candidate and the ray's far end)
 // within the kNearTie window of each other are flagged, because then the reference's visit order decides which one it
 // keeps.  Deferred subtrees that have fallen behind the best hit by the time they are popped are dropped without a fetch
@@ -54,6 +55,7 @@ PTD uint32_t wave_alloc(bool want, uint32_t* counter) {
 //   box_ready() / leaf_ready()     the next step is a box step / a triangle step
 //   finished()                     the query has ended
 //   inner(sc, st, wc), leaf(sc, st, wc)
+//   settle(sc, [bound,] wc)        once per query when the walk has ended: true = repeat it in reference order
 struct ClosestLane {
     typedef DistStack StackT;
     static constexpr int kSpillWords = 2 * kDistSpill;
@@ -70,7 +72,7 @@ struct ClosestLane {
     float tmax;
     float best, window;
     bool near_tie;
-    bool replay;       // the winner's parent box is entered beyond the window behind the winner: only the full reference-order query is safe
+    uint32_t hit_leaf;  // header slot of the leaf that holds the current winner
     HitD hit;
     uint32_t cur;
 
@@ -80,7 +82,7 @@ struct ClosestLane {
         tmax = ray.tmax;
         best = window = ray.tmax;
         near_tie = false;
-        replay = false;
+        hit_leaf = 0u;
         hit = HitD{-1, 0.0f, 0.0f, 0.0f};
         cur = sc.wide_root;
     }
@@ -136,42 +138,55 @@ struct ClosestLane {
             next(st);
     }
 
-    // a leaf: first the reference's own decision on the parent box (see box_cheap in traverse.h), then its triangles
+    // A leaf: its triangles are tried at once; whether the reference reaches this leaf at all (its decision on the leaf's
+    // parent box, see box_cheap in traverse.h) is settled once per ray, for the leaf of the final winner (settle()).  A
+    // candidate from a leaf the reference does not reach can only shrink the window to beyond the true winner's distance,
+    // so it never hides the true winner; if it ends up as the winner itself, settle() sends the ray to the full query.
     template <class C>
     PTD void leaf(const DevScene& sc, DistStack& st, C& wc) {
         const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
-        wc.tri();
-        float entry;
-        if (leaf_parent_accepts(sc, first, pre, tmax, entry)) {
-            for (uint32_t k = 0; k < count; ++k) {
-                V3 p0, e1, e2;
-                int32_t prim;
-                load_tri(sc, first + 1u + k, p0, e1, e2, prim);
-                wc.tri();
-                float t, u, v;
-                if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, window, t, u, v)) {
-                    near_tie = !(hit.prim < 0 || t * (1.0f + kNearTie) < best);
-                    if (hit.prim < 0 || t <= best) {
-                        best = t;
-                        hit.prim = prim;
-                        hit.t = t;
-                        hit.u = u;
-                        hit.v = v;
-                        // every bound the reference compares with an ancestor of this leaf is another candidate's distance
-                        // or the ray's far end, all beyond the window behind t (else near_tie / redo()); the ancestors'
-                        // entry distances are at most the parent's, so a parent entered within the window makes sure that
-                        // none of them is culled by such a bound
-                        replay = !(entry <= best * (1.0f + kNearTie));
-                        window = fminf(best * (1.0f + kNearTie), tmax);
-                    }
+        for (uint32_t k = 0; k < count; ++k) {
+            V3 p0, e1, e2;
+            int32_t prim;
+            load_tri(sc, first + 1u + k, p0, e1, e2, prim);
+            wc.tri();
+            float t, u, v;
+            if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, window, t, u, v)) {
+                near_tie = !(hit.prim < 0 || t * (1.0f + kNearTie) < best);
+                if (hit.prim < 0 || t <= best) {
+                    best = t;
+                    hit.prim = prim;
+                    hit.t = t;
+                    hit.u = u;
+                    hit.v = v;
+                    hit_leaf = first;
+                    window = fminf(best * (1.0f + kNearTie), tmax);
                 }
             }
         }
         next(st);
     }
 
-    PTD bool redo() const { return near_tie || replay || (hit.prim >= 0 && tmax < __builtin_huge_valf() && !(best * (1.0f + kNearTie) < tmax)); }
-    PTD float redo_bound() const { return (replay && hit.prim >= 0) ? kDeferExact : hit.t * (1.0f + 2.0f * kNearTie); }
+    // Called once when the walk has ended.  Returns true when the query has to be repeated in reference order, `bound` =
+    // how far (kDeferExact = all the way):
+    //  - the reference does not accept the parent box of the winner's leaf, so it never sees the winner: full query;
+    //  - it enters that box beyond the window behind the winner: every bound the reference compares with an ancestor of the
+    //    leaf is another candidate's distance or the ray's far end, all beyond the window (else near_tie below), and the
+    //    ancestors' entry distances are at most the parent's -- so a parent entered within the window makes sure that none
+    //    of them is culled by such a bound; otherwise only the full query is safe;
+    //  - two candidates, or the winner and the ray's far end, within the window of each other: the visit order decides.
+    template <class C>
+    PTD bool settle(const DevScene& sc, float& bound, C& wc) {
+        if (hit.prim < 0) return false;
+        wc.tri();
+        float entry;
+        if (!leaf_parent_accepts(sc, hit_leaf, pre, tmax, entry) || !(entry <= best * (1.0f + kNearTie))) {
+            bound = kDeferExact;
+            return true;
+        }
+        bound = hit.t * (1.0f + 2.0f * kNearTie);
+        return near_tie || (tmax < __builtin_huge_valf() && !(best * (1.0f + kNearTie) < tmax));
+    }
 };
 
 struct AnyLane {
@@ -190,6 +205,7 @@ struct AnyLane {
     float tmax;
     float far_end;  // tmax widened by the near-tie window: a box the ray enters beyond it is skipped
     bool occluded;
+    uint32_t hit_leaf;  // header slot of the leaf whose triangle ended the walk
     uint32_t cur;
 
     PTD void begin(const DevScene& sc, const RayD& ray, const RayPre& p) {
@@ -236,26 +252,37 @@ struct AnyLane {
             next(st);
     }
 
+    // the first accepted triangle ends the walk; whether the reference reaches its leaf is settled afterwards
     template <class C>
     PTD void leaf(const DevScene& sc, Stack& st, C& wc) {
         const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
-        wc.tri();
-        float entry;
-        if (leaf_parent_accepts(sc, first, pre, tmax, entry)) {
-            for (uint32_t k = 0; k < count; ++k) {
-                V3 p0, e1, e2;
-                int32_t prim;
-                load_tri(sc, first + 1u + k, p0, e1, e2, prim);
-                wc.tri();
-                float t, u, v;
-                if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, tmax, t, u, v)) {
-                    occluded = true;
-                    cur = kDone;
-                    return;
-                }
+        for (uint32_t k = 0; k < count; ++k) {
+            V3 p0, e1, e2;
+            int32_t prim;
+            load_tri(sc, first + 1u + k, p0, e1, e2, prim);
+            wc.tri();
+            float t, u, v;
+            if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, tmax, t, u, v)) {
+                occluded = true;
+                hit_leaf = first;
+                cur = kDone;
+                return;
             }
         }
         next(st);
+    }
+
+    // Called once when the walk has ended.  The reference reports "occluded" iff it reaches some leaf with an accepted
+    // triangle, i.e. iff it accepts that leaf's parent box.  If it does not accept the parent of the leaf found here,
+    // another leaf may still qualify: the ray is handed back and traced in reference order (true = defer).
+    template <class C>
+    PTD bool settle(const DevScene& sc, C& wc) {
+        if (!occluded) return false;
+        wc.tri();
+        float entry;
+        if (leaf_parent_accepts(sc, hit_leaf, pre, tmax, entry)) return false;
+        occluded = false;
+        return true;
     }
 };
 
@@ -330,8 +357,8 @@ struct ExactClosestLane {
         leaf_count = 0u;
         next(st);
     }
-    PTD bool redo() const { return false; }
-    PTD float redo_bound() const { return 0.0f; }
+    template <class C>
+    PTD bool settle(const DevScene&, float&, C&) { return false; }
 };
 
 struct ExactAnyLane {
@@ -397,8 +424,9 @@ struct ExactAnyLane {
         leaf_count = 0u;
         next(st);
     }
+    template <class C>
+    PTD bool settle(const DevScene&, C&) { return false; }
 };
-
 
 // lane states of the shared loop
 constexpr int kLaneEmpty = 0, kLaneBusy = 1, kLaneDone = 2;
@@ -484,8 +512,7 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
             if (state == kLaneBusy && L.leaf_ready()) L.leaf(sc, st, wc);
             if (state == kLaneBusy && L.finished()) {
                 state = kLaneDone;
-                defer = L.redo();
-                bound = L.redo_bound();
+                defer = L.settle(sc, bound, wc);
             }
             if (uint32_t(__popcll(__ballot(state == kLaneBusy))) < low) break;
         }
@@ -544,7 +571,10 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
                 if (n_inner < kMinBoxLanes) break;
             }
             if (state == kLaneBusy && L.leaf_ready()) L.leaf(sc, st, wc);
-            if (state == kLaneBusy && L.finished()) state = kLaneDone;
+            if (state == kLaneBusy && L.finished()) {
+                state = kLaneDone;
+                defer = L.settle(sc, wc);
+            }
             if (uint32_t(__popcll(__ballot(state == kLaneBusy))) < low) break;
         }
     }
