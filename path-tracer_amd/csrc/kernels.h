@@ -93,6 +93,11 @@ PTD bool last_block_of_shard(uint32_t* done, uint32_t shard) {
 #ifndef WPE
 #define WPE 6
 #endif
+// the camera-ray kernel carries the sampler and camera state on top of the traversal's: at 6 waves per SIMD it spills
+// 87 registers, at 5 it is 10 % (1.6 M triangles) to 30 % (3 K triangles) faster; at 4 about the same as at 5
+#ifndef WPE_GEN
+#define WPE_GEN 5
+#endif
 // LDS rows per lane of the kernels built on closest_wave: references and entry distances of its stack; the same memory
 // then serves the follow-up traversals of deferred rays as a plain stack of kLdsDepth rows.
 constexpr int kWaveRows = 2 * kDistRows;
@@ -349,7 +354,7 @@ struct GenerateIo {
 };
 
 template <class C, class Lane>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_generate_wave(DevScene sc, GenerateIo io,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE_GEN, WPE_GEN))) void k_generate_wave(DevScene sc, GenerateIo io,
                                                                                                                   uint32_t* fetch, uint32_t* done,
                                                                                                                   uint32_t* misc) {
     __shared__ uint32_t s_stack[kWaveRows * kBlock];

@@ -350,6 +350,25 @@ PTD void load_tri(const DevScene& sc, uint32_t slot, V3& p0, V3& e1, V3& e2, int
     prim = int32_t(as_u(a.w));
 }
 
+// One triangle record held in registers.  pin() is an empty instruction sequence that names all twelve words as
+// operands: the three 16-byte loads of fetch() then have to be issued before it, together, instead of the compiler
+// postponing the first vertex until the determinant test has passed (a second dependent memory round trip per triangle).
+struct TriRecord {
+    float4 a, b, c;
+    PTD void fetch(const DevScene& sc, uint32_t slot) {
+        a = sc.tris[3 * size_t(slot) + 0];
+        b = sc.tris[3 * size_t(slot) + 1];
+        c = sc.tris[3 * size_t(slot) + 2];
+    }
+    PTD void pin() {
+        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(c.x), "+v"(c.y), "+v"(c.z));
+    }
+    PTD V3 p0() const { return V3{a.x, a.y, a.z}; }
+    PTD V3 e1() const { return V3{b.x, b.y, b.z}; }
+    PTD V3 e2() const { return V3{c.x, c.y, c.z}; }
+    PTD int32_t prim() const { return int32_t(as_u(a.w)); }
+};
+
 // ------------------------------------------------------------------------------------------------ reference order
 
 // `bound` < +inf is only used when an ordered pass has already established that the nearest accepted triangle lies at

@@ -110,10 +110,10 @@ struct ClosestLane {
         const float inf = __builtin_huge_valf();
         const BoxC b0 = box_cheap(c0.x, c0.y, c0.z, cr), b1 = box_cheap(c1.x, c1.y, c1.z, cr);
         const BoxC b2 = box_cheap(c2.x, c2.y, c2.z, cr), b3 = box_cheap(c3.x, c3.y, c3.z, cr);
-        float k0 = (c0.w != kEmptyRef && cheap_go(b0, pre.tmin, window)) ? b0.tn : inf;
-        float k1 = (c1.w != kEmptyRef && cheap_go(b1, pre.tmin, window)) ? b1.tn : inf;
-        float k2 = (c2.w != kEmptyRef && cheap_go(b2, pre.tmin, window)) ? b2.tn : inf;
-        float k3 = (c3.w != kEmptyRef && cheap_go(b3, pre.tmin, window)) ? b3.tn : inf;
+        float k0 = (bool(c0.w != kEmptyRef) & cheap_go(b0, pre.tmin, window)) ? b0.tn : inf;
+        float k1 = (bool(c1.w != kEmptyRef) & cheap_go(b1, pre.tmin, window)) ? b1.tn : inf;
+        float k2 = (bool(c2.w != kEmptyRef) & cheap_go(b2, pre.tmin, window)) ? b2.tn : inf;
+        float k3 = (bool(c3.w != kEmptyRef) & cheap_go(b3, pre.tmin, window)) ? b3.tn : inf;
         uint32_t r0 = c0.w, r1 = c1.w, r2 = c2.w, r3 = c3.w;
         auto order = [](float& ka, uint32_t& ra, float& kb, uint32_t& rb) {  // afterwards ka <= kb
             const bool sw = kb < ka;
@@ -145,17 +145,20 @@ struct ClosestLane {
     template <class C>
     PTD void leaf(const DevScene& sc, DistStack& st, C& wc) {
         const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
+        // the next triangle's record is requested before the current one is tested (the last one is requested twice)
+        TriRecord nxt;
+        nxt.fetch(sc, first + 1u);
         for (uint32_t k = 0; k < count; ++k) {
-            V3 p0, e1, e2;
-            int32_t prim;
-            load_tri(sc, first + 1u + k, p0, e1, e2, prim);
+            TriRecord tr = nxt;
+            nxt.fetch(sc, first + 1u + min(k + 1u, count - 1u));
+            tr.pin();
             wc.tri();
             float t, u, v;
-            if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, window, t, u, v)) {
+            if (tri_hit(tr.p0(), tr.e1(), tr.e2(), pre.o, pre.d, pre.tmin, window, t, u, v)) {
                 near_tie = !(hit.prim < 0 || t * (1.0f + kNearTie) < best);
                 if (hit.prim < 0 || t <= best) {
                     best = t;
-                    hit.prim = prim;
+                    hit.prim = tr.prim();
                     hit.t = t;
                     hit.u = u;
                     hit.v = v;
@@ -226,10 +229,10 @@ struct AnyLane {
         const uint4* w = sc.qnodes + kWide * size_t(cur);
         wc.node();
         const uint4 c0 = w[0], c1 = w[1], c2 = w[2], c3 = w[3];
-        const bool g0 = c0.w != kEmptyRef && cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), pre.tmin, far_end);
-        const bool g1 = c1.w != kEmptyRef && cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), pre.tmin, far_end);
-        const bool g2 = c2.w != kEmptyRef && cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), pre.tmin, far_end);
-        const bool g3 = c3.w != kEmptyRef && cheap_go(box_cheap(c3.x, c3.y, c3.z, cr), pre.tmin, far_end);
+        const bool g0 = bool(c0.w != kEmptyRef) & cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), pre.tmin, far_end);
+        const bool g1 = bool(c1.w != kEmptyRef) & cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), pre.tmin, far_end);
+        const bool g2 = bool(c2.w != kEmptyRef) & cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), pre.tmin, far_end);
+        const bool g3 = bool(c3.w != kEmptyRef) & cheap_go(box_cheap(c3.x, c3.y, c3.z, cr), pre.tmin, far_end);
         // the order does not change the answer; slots are listed larger subtree first, as the builder orders children for
         // exactly this query (src/bvh.cpp:137-144), so the first slot is visited first and the last one pushed first
         uint32_t nxt = kDone;
@@ -256,13 +259,15 @@ struct AnyLane {
     template <class C>
     PTD void leaf(const DevScene& sc, Stack& st, C& wc) {
         const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
+        TriRecord nxt;
+        nxt.fetch(sc, first + 1u);
         for (uint32_t k = 0; k < count; ++k) {
-            V3 p0, e1, e2;
-            int32_t prim;
-            load_tri(sc, first + 1u + k, p0, e1, e2, prim);
+            TriRecord tr = nxt;
+            nxt.fetch(sc, first + 1u + min(k + 1u, count - 1u));
+            tr.pin();
             wc.tri();
             float t, u, v;
-            if (tri_hit(p0, e1, e2, pre.o, pre.d, pre.tmin, tmax, t, u, v)) {
+            if (tri_hit(tr.p0(), tr.e1(), tr.e2(), pre.o, pre.d, pre.tmin, tmax, t, u, v)) {
                 occluded = true;
                 hit_leaf = first;
                 cur = kDone;
