@@ -90,6 +90,7 @@ PTD bool last_block_of_shard(uint32_t* done, uint32_t shard) {
     return s_last != 0u;
 }
 
+// Waves per SIMD the wave-refill kernels are built for.
 #ifndef WPE
 #define WPE 6
 #endif
@@ -98,10 +99,6 @@ PTD bool last_block_of_shard(uint32_t* done, uint32_t shard) {
 #ifndef WPE_GEN
 #define WPE_GEN 5
 #endif
-// LDS rows per lane of the kernels built on closest_wave: references and entry distances of its stack; the same memory
-// then serves the follow-up traversals of deferred rays as a plain stack of kLdsDepth rows.
-constexpr int kWaveRows = 2 * kDistRows;
-static_assert(kWaveRows >= kLdsDepth, "the follow-up traversals use the same LDS as a plain stack");
 constexpr uint32_t kMaxWaveBlocks = 8;  // workgroups per shard of the wave-refill kernels: between 2 and 8, see wave_blocks()
 constexpr uint32_t kMinWaveBlocks = 2;
 constexpr uint32_t kShadeBlocks = 8;  // most workgroups per shard of k_shade (256 threads each), see shade_blocks()
@@ -270,6 +267,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
 // Ordered-mode k_generate: the "queue" of shard s is its kShard sample slots, a lane that takes slot j builds the camera
 // ray on the spot (closest_wave), and the result goes where k_generate puts it.
 struct GenerateIo {
+    static constexpr int kPhaseClass = 0;
     PassArgs pa;
     PathQ q;
     HitQ hq;
@@ -357,7 +355,7 @@ template <class C, class Lane>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE_GEN, WPE_GEN))) void k_generate_wave(DevScene sc, GenerateIo io,
                                                                                                                   uint32_t* fetch, uint32_t* done,
                                                                                                                   uint32_t* misc) {
-    __shared__ uint32_t s_stack[kWaveRows * kBlock];
+    __shared__ uint32_t s_stack[wave_lds_words<Lane>()];
     const uint32_t shard = shard_index();
     C wc;
     closest_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
@@ -389,6 +387,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE_GEN,
 // shard's hit list; a miss ends the path (src/integrator.cpp:53) and is simply not listed; deferred rays go to `dq` and are
 // finished by the shard's last workgroup.
 struct ExtendIo {
+    static constexpr int kPhaseClass = 1;
     PathQ q;
     HitQ hq;
     DeferQ dq;
@@ -456,7 +455,7 @@ PTD void extend_deferred(const DevScene& sc, const PathQ& q, const HitQ& hq, con
 template <class C, class Lane>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_extend_wave(DevScene sc, ExtendIo io, uint32_t* fetch,
                                                                                                     uint32_t* done, ZeroList zl, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kWaveRows * kBlock];
+    __shared__ uint32_t s_stack[wave_lds_words<Lane>()];
     const uint32_t shard = shard_index();
     zero_counters(zl, shard);
     C wc;
@@ -468,6 +467,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE
 // Visibility test of sampleLd (src/integrator.cpp:124-126) through any_wave, in either traversal order: unoccluded rays
 // add their contribution to the sample's radiance slot; plain-division rays go to `dq`.
 struct ShadowIo {
+    static constexpr int kPhaseClass = 2;
     ShadowQ sh;
     DeferQ dq;
     float4* lbuf;
@@ -502,7 +502,7 @@ struct ShadowIo {
 template <class C, class Lane>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_shadow_wave(DevScene sc, ShadowIo io, uint32_t* fetch,
                                                                                                     uint32_t* done, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    __shared__ uint32_t s_stack[wave_lds_words<Lane>()];
     const uint32_t shard = shard_index();
     C wc;
     any_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
@@ -533,6 +533,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE
 constexpr uint32_t kBatchDeferred = 0xfffffffeu;
 
 struct BatchClosestIo {
+    static constexpr int kPhaseClass = 3;
     const float4* rays;
     uint32_t n;
     float4* hits;
@@ -553,7 +554,7 @@ struct BatchClosestIo {
 
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_intersect_wave(DevScene sc, BatchClosestIo io, uint32_t* fetch, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kWaveRows * kBlock];
+    __shared__ uint32_t s_stack[wave_lds_words<ClosestLane>()];
     C wc;
     closest_wave<ClosestLane>(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
     flush_counts(wc, misc, 1);
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_fix(DevScene sc, const flo
 }
 
 struct BatchAnyIo {
+    static constexpr int kPhaseClass = 3;
     const float4* rays;
     uint32_t n;
     uint8_t* occ;
@@ -595,7 +597,7 @@ struct BatchAnyIo {
 
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_occluded_wave(DevScene sc, BatchAnyIo io, uint32_t* fetch, uint32_t* misc) {
-    __shared__ uint32_t s_stack[kLdsDepth * kBlock];
+    __shared__ uint32_t s_stack[wave_lds_words<AnyLane>()];
     C wc;
     any_wave<AnyLane>(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
     flush_counts(wc, misc, 2);

@@ -1593,3 +1593,15 @@ int pt_hip_sobol(pt_hip_scene* s, const int32_t* pixel_xy, const uint32_t* sampl
 }
 
 }  // extern "C"
+
+#ifdef PT_PHASE_STATS
+// diagnostic builds only (not declared in the public header): reads, and optionally clears, the phase counters
+extern "C" int pt_hip_debug_phase(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_phase), sizeof(ptd::g_phase)) != hipSuccess) return -1;
+    if (reset) {
+        static const unsigned long long zero[4][8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_phase), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

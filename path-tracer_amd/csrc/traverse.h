@@ -32,9 +32,6 @@ constexpr int kBlock = 128;      // threads per workgroup of every traversal ker
 #ifndef PT_LDS_DEPTH
 #define PT_LDS_DEPTH 24
 #endif
-#ifndef PT_DIST_ROWS
-#define PT_DIST_ROWS 12
-#endif
 constexpr int kLdsDepth = PT_LDS_DEPTH;    // stack entries per lane in LDS
 constexpr int kSpillDepth = 72;  // further entries per lane in scratch
 constexpr int kMaxStack = kLdsDepth + kSpillDepth;
@@ -43,9 +40,12 @@ constexpr int kMaxStack = kLdsDepth + kSpillDepth;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(5))) uint32_t private_u32;
 
-struct Stack {
+template <int ROWS>
+struct StackN {
+    static constexpr int kRows = ROWS;            // entries per lane in LDS
+    static constexpr int kSpill = kMaxStack - ROWS;  // further entries per lane in scratch
     lds_u32* lds;        // &shared[0][threadIdx.x]
-    private_u32* spill;  // kSpillDepth private words, declared by the function that owns the stack (kept out of this
+    private_u32* spill;  // kSpill private words, declared by the function that owns the stack (kept out of this
                          // struct so that the compiler keeps everything but the array itself in registers)
     int sp;
     PTD void init(uint32_t* base, uint32_t* spill_words) {
@@ -54,29 +54,30 @@ struct Stack {
         sp = 0;
     }
     PTD void push(uint32_t v) {
-        if (sp < kLdsDepth)
+        if (sp < ROWS)
             lds[sp * kBlock] = v;
         else
-            spill[sp - kLdsDepth] = v;
+            spill[sp - ROWS] = v;
         ++sp;
     }
     PTD uint32_t pop() {
         --sp;
-        return (sp < kLdsDepth) ? lds[sp * kBlock] : spill[sp - kLdsDepth];
+        return (sp < ROWS) ? lds[sp * kBlock] : spill[sp - ROWS];
     }
     PTD bool empty() const { return sp == 0; }
 };
+typedef StackN<kLdsDepth> Stack;
 
 // Stack of the wave-level ordered closest-hit traversal: a deferred subtree is kept together with the distance at which
 // the ray enters its box, so that a subtree that lies beyond the best hit by the time it is popped is dropped without
-// its node being fetched.  kDistRows entries per lane in LDS (references in rows [0, kDistRows), distances in rows
-// [kDistRows, 2 kDistRows) of a [row][lane] array), the rest in two private arrays.
-constexpr int kDistRows = PT_DIST_ROWS;
-constexpr int kDistSpill = kMaxStack - kDistRows;
-
-struct DistStack {
+// its node being fetched.  ROWS entries per lane in LDS (references in rows [0, ROWS), distances in rows
+// [ROWS, 2 ROWS) of a [row][lane] array), the rest in two private arrays.
+template <int ROWS>
+struct DistStackN {
+    static constexpr int kRows = ROWS;
+    static constexpr int kSpill = kMaxStack - ROWS;
     lds_u32* lds;
-    private_u32* spill;    // kDistSpill references, then kDistSpill distances
+    private_u32* spill;    // kSpill references, then kSpill distances
     int sp;
     PTD void init(uint32_t* base, uint32_t* spill_words) {
         lds = (lds_u32*)base;
@@ -84,27 +85,39 @@ struct DistStack {
         sp = 0;
     }
     PTD void push(uint32_t v, float d) {
-        if (sp < kDistRows) {
+        if (sp < ROWS) {
             lds[sp * kBlock] = v;
-            lds[(sp + kDistRows) * kBlock] = __float_as_uint(d);
+            lds[(sp + ROWS) * kBlock] = __float_as_uint(d);
         } else {
-            spill[sp - kDistRows] = v;
-            spill[sp - kDistRows + kDistSpill] = __float_as_uint(d);
+            spill[sp - ROWS] = v;
+            spill[sp - ROWS + kSpill] = __float_as_uint(d);
         }
         ++sp;
     }
     PTD void pop(uint32_t& v, float& d) {
         --sp;
-        if (sp < kDistRows) {
+        if (sp < ROWS) {
             v = lds[sp * kBlock];
-            d = __uint_as_float(lds[(sp + kDistRows) * kBlock]);
+            d = __uint_as_float(lds[(sp + ROWS) * kBlock]);
         } else {
-            v = spill[sp - kDistRows];
-            d = __uint_as_float(spill[sp - kDistRows + kDistSpill]);
+            v = spill[sp - ROWS];
+            d = __uint_as_float(spill[sp - ROWS + kSpill]);
         }
     }
     PTD bool empty() const { return sp == 0; }
 };
+
+// LDS rows of the ordered traversals' stacks (closest hit: references and entry distances, kDistRows each)
+#ifndef PT_DIST_ROWS
+#define PT_DIST_ROWS 12
+#endif
+#ifndef PT_ANY_ROWS
+#define PT_ANY_ROWS 24
+#endif
+constexpr int kDistRows = PT_DIST_ROWS;
+constexpr int kAnyRows = PT_ANY_ROWS;
+typedef DistStackN<kDistRows> DistStack;
+typedef StackN<kAnyRows> AnyStack;
 
 struct RayD {
     V3 o, d;

@@ -48,6 +48,45 @@ PTD uint32_t wave_alloc(bool want, uint32_t* counter) {
     return base + uint32_t(__popcll(mask & ((1ull << lane_id()) - 1ull)));
 }
 
+// Diagnostic builds (-DPT_PHASE_STATS) count, per kernel class, how many lanes take part in each phase of the shared
+// loops: [0] box steps of a wave, [1] lanes in them, [2] leaf phases, [3] lanes in them, [4] triangle-loop rounds,
+// [5] lane-triangles, [6] commit/fetch rounds, [7] lanes committed.  Compiles to nothing otherwise.
+#ifdef PT_PHASE_STATS
+__device__ unsigned long long g_phase[4][8];
+struct PhaseStats {
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PTD void box(uint32_t lanes) {
+        c[0] += 1;
+        c[1] += lanes;
+    }
+    PTD void leaf(bool active, uint32_t cur) {
+        const uint32_t count = active ? ((cur >> kLeafCountShift) & 15u) : 0u;
+        c[2] += 1;
+        c[3] += uint32_t(__popcll(__ballot(active)));
+        for (uint32_t k = 0; k < 15u; ++k) {
+            const uint32_t n = uint32_t(__popcll(__ballot(count > k)));
+            c[4] += n != 0u;
+            c[5] += n;
+        }
+    }
+    PTD void round(bool fin) {
+        c[6] += 1;
+        c[7] += uint32_t(__popcll(__ballot(fin)));
+    }
+    PTD void flush(int cls) {
+        if (lane_id() == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(&g_phase[cls][i], c[i]);
+    }
+};
+#else
+struct PhaseStats {
+    PTD void box(uint32_t) {}
+    PTD void leaf(bool, uint32_t) {}
+    PTD void round(bool) {}
+    PTD void flush(int) {}
+};
+#endif
+
 // Lane interface of the shared loops (closest_wave / any_wave):
 //   StackT, kSpillWords            the lane's stack type and the private words it needs
 //   idle()                         put the lane into the "nothing to do" state
@@ -58,7 +97,8 @@ PTD uint32_t wave_alloc(bool want, uint32_t* counter) {
 //   settle(sc, [bound,] wc)        once per query when the walk has ended: true = repeat it in reference order
 struct ClosestLane {
     typedef DistStack StackT;
-    static constexpr int kSpillWords = 2 * kDistSpill;
+    static constexpr int kSpillWords = 2 * DistStack::kSpill;
+    static constexpr int kLdsRows = 2 * DistStack::kRows;
     static constexpr bool kReferenceOrder = false;
     PTD void idle() {
         cur = kDone;
@@ -67,20 +107,24 @@ struct ClosestLane {
     PTD bool box_ready() const { return !(cur >> 31); }
     PTD bool leaf_ready() const { return cur > kDone; }
     PTD bool finished() const { return cur == kDone; }
-    RayPre pre;
+    PTD const V3& org() const { return o; }
+    PTD const V3& dir() const { return d; }
+    V3 o, d;
     CheapRay cr;
-    float tmax;
-    float best, window;
+    float tmin, tmax;
+    float window;       // candidates are accepted up to here: the best hit's distance widened by kNearTie, or the ray's far end
     bool near_tie;
     uint32_t hit_leaf;  // header slot of the leaf that holds the current winner
     HitD hit;
     uint32_t cur;
 
     PTD void begin(const DevScene& sc, const RayD& ray, const RayPre& p) {
-        pre = p;
+        o = p.o;
+        d = p.d;
+        tmin = p.tmin;
         cr.set(sc, p);
         tmax = ray.tmax;
-        best = window = ray.tmax;
+        window = ray.tmax;
         near_tie = false;
         hit_leaf = 0u;
         hit = HitD{-1, 0.0f, 0.0f, 0.0f};
@@ -110,10 +154,10 @@ struct ClosestLane {
         const float inf = __builtin_huge_valf();
         const BoxC b0 = box_cheap(c0.x, c0.y, c0.z, cr), b1 = box_cheap(c1.x, c1.y, c1.z, cr);
         const BoxC b2 = box_cheap(c2.x, c2.y, c2.z, cr), b3 = box_cheap(c3.x, c3.y, c3.z, cr);
-        float k0 = (bool(c0.w != kEmptyRef) & cheap_go(b0, pre.tmin, window)) ? b0.tn : inf;
-        float k1 = (bool(c1.w != kEmptyRef) & cheap_go(b1, pre.tmin, window)) ? b1.tn : inf;
-        float k2 = (bool(c2.w != kEmptyRef) & cheap_go(b2, pre.tmin, window)) ? b2.tn : inf;
-        float k3 = (bool(c3.w != kEmptyRef) & cheap_go(b3, pre.tmin, window)) ? b3.tn : inf;
+        float k0 = (bool(c0.w != kEmptyRef) & cheap_go(b0, tmin, window)) ? b0.tn : inf;
+        float k1 = (bool(c1.w != kEmptyRef) & cheap_go(b1, tmin, window)) ? b1.tn : inf;
+        float k2 = (bool(c2.w != kEmptyRef) & cheap_go(b2, tmin, window)) ? b2.tn : inf;
+        float k3 = (bool(c3.w != kEmptyRef) & cheap_go(b3, tmin, window)) ? b3.tn : inf;
         uint32_t r0 = c0.w, r1 = c1.w, r2 = c2.w, r3 = c3.w;
         auto order = [](float& ka, uint32_t& ra, float& kb, uint32_t& rb) {  // afterwards ka <= kb
             const bool sw = kb < ka;
@@ -154,16 +198,15 @@ struct ClosestLane {
             tr.pin();
             wc.tri();
             float t, u, v;
-            if (tri_hit(tr.p0(), tr.e1(), tr.e2(), pre.o, pre.d, pre.tmin, window, t, u, v)) {
-                near_tie = !(hit.prim < 0 || t * (1.0f + kNearTie) < best);
-                if (hit.prim < 0 || t <= best) {
-                    best = t;
+            if (tri_hit(tr.p0(), tr.e1(), tr.e2(), o, d, tmin, window, t, u, v)) {
+                near_tie = !(hit.prim < 0 || t * (1.0f + kNearTie) < hit.t);
+                if (hit.prim < 0 || t <= hit.t) {
                     hit.prim = tr.prim();
                     hit.t = t;
                     hit.u = u;
                     hit.v = v;
                     hit_leaf = first;
-                    window = fminf(best * (1.0f + kNearTie), tmax);
+                    window = fminf(t * (1.0f + kNearTie), tmax);
                 }
             }
         }
@@ -182,19 +225,22 @@ struct ClosestLane {
     PTD bool settle(const DevScene& sc, float& bound, C& wc) {
         if (hit.prim < 0) return false;
         wc.tri();
+        // the ray's reciprocals are only needed here, once per query, and are recomputed rather than kept
+        const RayPre pre = make_pre(sc, RayD{o, d, tmin, tmax});
         float entry;
-        if (!leaf_parent_accepts(sc, hit_leaf, pre, tmax, entry) || !(entry <= best * (1.0f + kNearTie))) {
+        if (!leaf_parent_accepts(sc, hit_leaf, pre, tmax, entry) || !(entry <= hit.t * (1.0f + kNearTie))) {
             bound = kDeferExact;
             return true;
         }
         bound = hit.t * (1.0f + 2.0f * kNearTie);
-        return near_tie || (tmax < __builtin_huge_valf() && !(best * (1.0f + kNearTie) < tmax));
+        return near_tie || (tmax < __builtin_huge_valf() && !(hit.t * (1.0f + kNearTie) < tmax));
     }
 };
 
 struct AnyLane {
-    typedef Stack StackT;
-    static constexpr int kSpillWords = kSpillDepth;
+    typedef AnyStack StackT;
+    static constexpr int kSpillWords = AnyStack::kSpill;
+    static constexpr int kLdsRows = AnyStack::kRows;
     static constexpr bool kReferenceOrder = false;
     PTD void idle() {
         cur = kDone;
@@ -203,36 +249,39 @@ struct AnyLane {
     PTD bool box_ready() const { return !(cur >> 31); }
     PTD bool leaf_ready() const { return cur > kDone; }
     PTD bool finished() const { return cur == kDone; }
-    RayPre pre;
+    V3 o, d;
     CheapRay cr;
-    float tmax;
+    float tmin, tmax;
     float far_end;  // tmax widened by the near-tie window: a box the ray enters beyond it is skipped
     bool occluded;
     uint32_t hit_leaf;  // header slot of the leaf whose triangle ended the walk
     uint32_t cur;
 
     PTD void begin(const DevScene& sc, const RayD& ray, const RayPre& p) {
-        pre = p;
+        o = p.o;
+        d = p.d;
+        tmin = p.tmin;
         cr.set(sc, p);
         tmax = ray.tmax;
         far_end = ray.tmax * (1.0f + kNearTie);
         occluded = false;
+        hit_leaf = 0u;
         cur = sc.wide_root;
     }
-    PTD void next(Stack& st) { cur = st.empty() ? kDone : st.pop(); }
+    PTD void next(AnyStack& st) { cur = st.empty() ? kDone : st.pop(); }
 
     // The reference's bound is constant for this query, so the leaves it reaches do not depend on the visit order: it
     // reaches a leaf iff it accepts the leaf's parent box.  Any walk that visits every such leaf that can hold an accepted
     // triangle, and tries a leaf's triangles only after the parent's exact test, returns what the reference returns.
     template <class C>
-    PTD void inner(const DevScene& sc, Stack& st, C& wc) {
+    PTD void inner(const DevScene& sc, AnyStack& st, C& wc) {
         const uint4* w = sc.qnodes + kWide * size_t(cur);
         wc.node();
         const uint4 c0 = w[0], c1 = w[1], c2 = w[2], c3 = w[3];
-        const bool g0 = bool(c0.w != kEmptyRef) & cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), pre.tmin, far_end);
-        const bool g1 = bool(c1.w != kEmptyRef) & cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), pre.tmin, far_end);
-        const bool g2 = bool(c2.w != kEmptyRef) & cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), pre.tmin, far_end);
-        const bool g3 = bool(c3.w != kEmptyRef) & cheap_go(box_cheap(c3.x, c3.y, c3.z, cr), pre.tmin, far_end);
+        const bool g0 = bool(c0.w != kEmptyRef) & cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), tmin, far_end);
+        const bool g1 = bool(c1.w != kEmptyRef) & cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), tmin, far_end);
+        const bool g2 = bool(c2.w != kEmptyRef) & cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), tmin, far_end);
+        const bool g3 = bool(c3.w != kEmptyRef) & cheap_go(box_cheap(c3.x, c3.y, c3.z, cr), tmin, far_end);
         // the order does not change the answer; slots are listed larger subtree first, as the builder orders children for
         // exactly this query (src/bvh.cpp:137-144), so the first slot is visited first and the last one pushed first
         uint32_t nxt = kDone;
@@ -257,7 +306,7 @@ struct AnyLane {
 
     // the first accepted triangle ends the walk; whether the reference reaches its leaf is settled afterwards
     template <class C>
-    PTD void leaf(const DevScene& sc, Stack& st, C& wc) {
+    PTD void leaf(const DevScene& sc, AnyStack& st, C& wc) {
         const uint32_t first = cur & kLeafFirstMask, count = (cur >> kLeafCountShift) & 15u;
         TriRecord nxt;
         nxt.fetch(sc, first + 1u);
@@ -267,7 +316,7 @@ struct AnyLane {
             tr.pin();
             wc.tri();
             float t, u, v;
-            if (tri_hit(tr.p0(), tr.e1(), tr.e2(), pre.o, pre.d, pre.tmin, tmax, t, u, v)) {
+            if (tri_hit(tr.p0(), tr.e1(), tr.e2(), o, d, tmin, tmax, t, u, v)) {
                 occluded = true;
                 hit_leaf = first;
                 cur = kDone;
@@ -284,6 +333,7 @@ struct AnyLane {
     PTD bool settle(const DevScene& sc, C& wc) {
         if (!occluded) return false;
         wc.tri();
+        const RayPre pre = make_pre(sc, RayD{o, d, tmin, tmax});
         float entry;
         if (leaf_parent_accepts(sc, hit_leaf, pre, tmax, entry)) return false;
         occluded = false;
@@ -303,8 +353,11 @@ constexpr uint32_t kNoNode = 0xffffffffu;
 struct ExactClosestLane {
     typedef Stack StackT;
     static constexpr int kSpillWords = kSpillDepth;
+    static constexpr int kLdsRows = kLdsDepth;
     static constexpr bool kReferenceOrder = true;
     RayPre pre;
+    PTD const V3& org() const { return pre.o; }
+    PTD const V3& dir() const { return pre.d; }
     float max_dis;
     HitD hit;
     uint32_t cur;                      // binary node to fetch next, or kNoNode
@@ -369,6 +422,7 @@ struct ExactClosestLane {
 struct ExactAnyLane {
     typedef Stack StackT;
     static constexpr int kSpillWords = kSpillDepth;
+    static constexpr int kLdsRows = kLdsDepth;
     static constexpr bool kReferenceOrder = true;
     RayPre pre;
     float tmax;
@@ -456,7 +510,11 @@ PTD uint32_t wave_fetch(bool want, uint32_t* counter, uint32_t count, bool& more
 //   bool load(sc, shard, j, RayD&, Carry&)                     ray j and whatever the caller wants back at commit time;
 //                                                           false = position j holds no query (reported as a miss)
 //   void commit(sc, shard, fin, j, hit, defer, bound, carry, o, d)   called by the whole wave; fin marks lanes with a result
-// lds_stack: this lane's column of a [2 * kDistRows][kBlock] array of words.
+// lds_stack: this lane's column of a [Lane::kLdsRows][kBlock] array of words.
+//
+// A query whose walk has ended stays in its lane until the next refill; settle() and commit() then run once for all
+// lanes that have a result (run per loop round for the one or two lanes that just ended, settle() -- an exact box
+// decision behind a dependent fetch -- cost as much as a box step of the whole wave).
 template <class Lane, class Io, class C>
 PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, C& wc) {
     const uint32_t count = io.count(shard);
@@ -470,10 +528,15 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
     int state = kLaneEmpty;
     bool defer = false, more = true;
     float bound = 0.0f;
+    PhaseStats ps;
     for (;;) {
-        if (__any(state == kLaneDone)) {
-            io.commit(sc, shard, state == kLaneDone, j, L.hit, defer, bound, carry, L.pre.o, L.pre.d);
-            if (state == kLaneDone) state = kLaneEmpty;
+        const bool walked = state == kLaneBusy && L.finished();
+        const bool fin = walked || state == kLaneDone;
+        if (__any(fin)) {
+            ps.round(fin);
+            if (walked) defer = L.settle(sc, bound, wc);
+            io.commit(sc, shard, fin, j, L.hit, defer, bound, carry, L.org(), L.dir());
+            if (fin) state = kLaneEmpty;
         }
         if (more) {
             const bool want = state == kLaneEmpty;
@@ -483,16 +546,15 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
                 RayD ray;
                 const bool has_ray = io.load(sc, shard, j, ray, carry);
                 const RayPre pre = make_pre(sc, ray);
-                L.pre = pre;
                 if (!has_ray) {  // a queue position without a query (a pixel slot outside the image)
                     state = kLaneDone;
                     defer = false;
-                    L.hit.prim = -1;
+                    L.idle();
                 } else if (pre.special) {
                     state = kLaneDone;
                     defer = true;
                     bound = kDeferExact;
-                    L.hit.prim = -1;
+                    L.idle();
                 } else {
                     L.begin(sc, ray, pre);
                     st.sp = 0;
@@ -511,17 +573,16 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
                 const bool inner = state == kLaneBusy && L.box_ready();
                 const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
                 if (n_inner == 0u) break;
+                ps.box(n_inner);
                 if (inner) L.inner(sc, st, wc);
                 if (n_inner < kMinBoxLanes) break;
             }
+            if constexpr (!Lane::kReferenceOrder) ps.leaf(state == kLaneBusy && L.leaf_ready(), L.cur);
             if (state == kLaneBusy && L.leaf_ready()) L.leaf(sc, st, wc);
-            if (state == kLaneBusy && L.finished()) {
-                state = kLaneDone;
-                defer = L.settle(sc, bound, wc);
-            }
-            if (uint32_t(__popcll(__ballot(state == kLaneBusy))) < low) break;
+            if (uint32_t(__popcll(__ballot(state == kLaneBusy && !L.finished()))) < low) break;
         }
     }
+    ps.flush(Io::kPhaseClass);
 }
 
 // Any hit for the rays of one shard.  Io: count(shard), load(sc, shard, j, RayD&, Carry&),
@@ -538,10 +599,15 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
     uint32_t j = 0;
     int state = kLaneEmpty;
     bool defer = false, more = true;
+    PhaseStats ps;
     for (;;) {
-        if (__any(state == kLaneDone)) {
-            io.commit(sc, shard, state == kLaneDone, j, L.occluded, defer, carry);
-            if (state == kLaneDone) state = kLaneEmpty;
+        const bool walked = state == kLaneBusy && L.finished();
+        const bool fin = walked || state == kLaneDone;
+        if (__any(fin)) {
+            ps.round(fin);
+            if (walked) defer = L.settle(sc, wc);
+            io.commit(sc, shard, fin, j, L.occluded, defer, carry);
+            if (fin) state = kLaneEmpty;
         }
         if (more) {
             const bool want = state == kLaneEmpty;
@@ -554,6 +620,7 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
                 if (pre.special) {
                     state = kLaneDone;
                     defer = true;
+                    L.idle();
                 } else {
                     L.begin(sc, ray, pre);
                     st.sp = 0;
@@ -572,17 +639,23 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
                 const bool inner = state == kLaneBusy && L.box_ready();
                 const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
                 if (n_inner == 0u) break;
+                ps.box(n_inner);
                 if (inner) L.inner(sc, st, wc);
                 if (n_inner < kMinBoxLanes) break;
             }
+            if constexpr (!Lane::kReferenceOrder) ps.leaf(state == kLaneBusy && L.leaf_ready(), L.cur);
             if (state == kLaneBusy && L.leaf_ready()) L.leaf(sc, st, wc);
-            if (state == kLaneBusy && L.finished()) {
-                state = kLaneDone;
-                defer = L.settle(sc, wc);
-            }
-            if (uint32_t(__popcll(__ballot(state == kLaneBusy))) < low) break;
+            if (uint32_t(__popcll(__ballot(state == kLaneBusy && !L.finished()))) < low) break;
         }
     }
+    ps.flush(Io::kPhaseClass);
+}
+
+// LDS words per workgroup of a kernel built on the wave loops for lane type Lane; the follow-up traversals of deferred
+// rays use the same memory as a plain stack of kLdsDepth rows
+template <class Lane>
+constexpr int wave_lds_words() {
+    return (Lane::kLdsRows > kLdsDepth ? Lane::kLdsRows : kLdsDepth) * kBlock;
 }
 
 }  // namespace ptd
