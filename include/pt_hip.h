@@ -120,9 +120,9 @@ typedef struct pt_hit {
  * current max distance, never box-test leaves, accept t <= max, last accepted wins.
  * FAST is an ordered (nearest slot first, distance-culled) traversal of a 4-wide node layout collapsed from the same tree,
  * with slot boxes quantised outwards to 16 bits.  Interior nodes are only navigated, with a conservative slab test; the
- * reference's own box decision is taken once per visited leaf, on the leaf's parent box, which decides whether the
- * reference reaches that leaf at all (its slab test, src/aabb.cpp:6-35, is monotone under box nesting: a ray that it
- * accepts for a box it accepts for every enclosing box).  A query is repeated in the reference's order whenever two
+ * reference's own box decision is taken once per query, on the parent box of the leaf that holds the result, which decides
+ * whether the reference reaches that leaf at all (its slab test, src/aabb.cpp:6-35, is monotone under box nesting: a ray
+ * that it accepts for a box it accepts for every enclosing box).  A query is repeated in the reference's order whenever two
  * candidates (or a candidate and the ray's far end) lie within a 2^-13 relative distance of each other, and rays with a
  * zero, tiny, huge or non-finite direction component are traced in the reference's order from the start, so that the
  * reported triangle, t, u and v are the reference's in both modes; occlusion queries are order-independent by

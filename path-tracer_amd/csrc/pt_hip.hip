@@ -1,8 +1,9 @@
 // libpt_hip.so: C ABI (include/pt_hip.h) over the HIP kernels in kernels.h.
 //
-// Host-side responsibilities: validate the flat scene description, flatten the host-built binary BVH into the two
-// device layouts (reference-order nodes and the ordered 2-wide nodes), build the Sobol' look-up tables, own the
-// per-pass work buffers, and drive the wavefront loop (generate -> [shade -> shadow + extend]* -> film).
+// Host-side responsibilities: validate the flat scene description, flatten the binary BVH (handed in, or built here by
+// pt_hip_build_bvh) into the two device layouts (reference-order nodes and the 4-wide navigation nodes of the ordered
+// traversal), build the Sobol' look-up tables, own the per-pass work buffers, and drive the wavefront loop
+// (generate -> [shade -> shadow + extend]* -> film).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,4 +1,4 @@
-// BVH traversal for wave64: reference-order ("exact") and ordered 2-wide ("fast") closest-hit / any-hit.
+// BVH traversal for wave64: reference-order ("exact") and ordered 4-wide ("fast") closest-hit / any-hit.
 //
 // Reference behaviour being reproduced (paths relative to the reference root):
 //   src/bvh.cpp:26-59   closest hit: explicit stack, pop a node, leaves are never box-tested, interior nodes are culled
@@ -15,9 +15,9 @@
 //     component are "special" and take the plain IEEE division so that the NaN / infinity cases come out as in the
 //     reference, and so does any box for which one of the quotient estimates is zero or tiny;
 //   - the ordered mode (traverse_wave.h) navigates with a conservative test and takes this exact decision once per
-//     visited leaf, on the leaf's parent box (see box_cheap below for why that is enough); it differs from the reference
-//     only in the ORDER in which subtrees are visited and in culling by distance, and falls back to the reference order
-//     whenever order could matter.
+//     query, on the parent box of the leaf that holds the result (see box_cheap below for why that is enough); it differs
+//     from the reference only in the ORDER in which subtrees are visited and in culling by distance, and falls back to
+//     the reference order whenever order could matter.
 //
 // Per-lane traversal stack: the first kLdsDepth entries live in LDS, laid out [entry][lane] so that a wave's 64 lanes
 // hit 64 consecutive banks; deeper entries spill to a private (scratch) array.  The host rejects trees deeper than

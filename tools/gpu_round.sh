@@ -18,3 +18,5 @@ bash tools/gpu_prof.sh ${TAG}_library --workload library-synth --spp 512 --trave
 python3 tools/prof_summary.py $O/prof_${TAG}_library > $O/${TAG}_prof_library_fast.txt || exit 9
 bash tools/gpu_prof.sh ${TAG}_veach --workload veach-mis --spp 512 --traversal fast || exit 10
 python3 tools/prof_summary.py $O/prof_${TAG}_veach > $O/${TAG}_prof_veach_fast.txt || exit 11
+# the rocprofv3 databases are not needed once summarised (and a call may bring back 64 MiB at most)
+rm -rf $O/prof_${TAG}_bench $O/prof_${TAG}_library $O/prof_${TAG}_veach
