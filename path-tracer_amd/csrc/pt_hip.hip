@@ -337,17 +337,27 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     DevScene& dev = s->dev;
     PhaseClock clk;
     // Leaf array: every leaf is a header record (its parent's box, see leaf_parent_accepts) followed by its triangles
-    // {p0, prim} {e1} {e2}; slot_of[i] = header slot of leaf node i.
-    // (slot_of has one entry more than there are nodes: the slots of nodes [0, i) -- interior nodes take none)
+    // {p0, prim} {e1} {e2}.  An interior node whose two children are both leaves with at most kFatLeafTris triangles
+    // between them is a FAT LEAF of the ordered traversal: its children lie next to each other in node order and have the
+    // same parent box, so the second one goes without a header and the pair reads as one leaf (traverse.h, fat leaves).
+    // slot_of[i] = first record of leaf node i (its header, or its first triangle when it has none); one entry more than
+    // there are nodes: the records of nodes [0, i) -- interior nodes take none.
     std::vector<uint32_t> slot_of(size_t(d->n_nodes) + 1, 0), parent(d->n_nodes, 0);
+    std::vector<uint8_t> fat(d->n_nodes, 0);
+    for (uint32_t i = 0; i < d->n_nodes; ++i) {
+        const pt_bvh_node& b = d->nodes[i];
+        if (b.count) continue;
+        parent[b.first] = parent[b.first + 1] = i;
+        const uint32_t ca = d->nodes[b.first].count, cb = d->nodes[b.first + 1].count;
+        fat[i] = (ca != 0u && cb != 0u && ca + cb <= kFatLeafTris) ? 1 : 0;
+    }
+    // the second child of a fat leaf: no header of its own
+    auto headless = [&](uint32_t i) { return i != 0u && fat[parent[i]] && i == d->nodes[parent[i]].first + 1u; };
     uint64_t n_slots64 = 0;
     for (uint32_t i = 0; i < d->n_nodes; ++i) {
         const pt_bvh_node& b = d->nodes[i];
         slot_of[i] = uint32_t(n_slots64);
-        if (b.count)
-            n_slots64 += 1u + b.count;
-        else
-            parent[b.first] = parent[b.first + 1] = i;
+        if (b.count) n_slots64 += (headless(i) ? 0u : 1u) + b.count;
     }
     if (n_slots64 > kLeafFirstMask) return fail(PT_ERR_LIMIT, "triangles + leaves exceed 2^27-1 leaf-array records");
     slot_of[d->n_nodes] = uint32_t(n_slots64);
@@ -356,7 +366,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     if (int rc = fill_upload<float4>(
             s, d->n_nodes, [](size_t u) { return 2 * u; }, &dev.nodes, [&](size_t i, float4* o) {
                 const pt_bvh_node& b = d->nodes[i];
-                uint32_t first = b.count ? slot_of[i] + 1u : b.first, count = b.count;
+                uint32_t first = b.count ? slot_of[i] + (headless(uint32_t(i)) ? 0u : 1u) : b.first, count = b.count;
                 float ff, fc;
                 std::memcpy(&ff, &first, 4);
                 std::memcpy(&fc, &count, 4);
@@ -369,13 +379,16 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             s, d->n_nodes, [&](size_t u) { return 3 * size_t(slot_of[u]); }, &dev.tris, [&](size_t i, float4* h) {
                 const pt_bvh_node& b = d->nodes[i];
                 if (!b.count) return;
-                const uint32_t flags = (i == 0) ? kLeafUntested : 0u;
-                float ffl;
-                std::memcpy(&ffl, &flags, 4);
-                const pt_bvh_node& pb = d->nodes[parent[i]];
-                h[0] = make_float4(pb.lo[0], pb.lo[1], pb.lo[2], pb.hi[0]);
-                h[1] = make_float4(pb.hi[1], pb.hi[2], ffl, 0.0f);
-                h[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (!headless(uint32_t(i))) {
+                    const uint32_t flags = (i == 0) ? kLeafUntested : 0u;
+                    float ffl;
+                    std::memcpy(&ffl, &flags, 4);
+                    const pt_bvh_node& pb = d->nodes[parent[i]];
+                    h[0] = make_float4(pb.lo[0], pb.lo[1], pb.lo[2], pb.hi[0]);
+                    h[1] = make_float4(pb.hi[1], pb.hi[2], ffl, 0.0f);
+                    h[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    h += 3;
+                }
                 for (uint32_t k = 0; k < b.count; ++k) {
                     const uint32_t prim = d->prim_ids[b.first + k];
                     const float* p0 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 0] - 1);
@@ -383,7 +396,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
                     const float* p2 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 2] - 1);
                     float fp;
                     std::memcpy(&fp, &prim, 4);
-                    float4* o = h + 3 * size_t(1u + k);
+                    float4* o = h + 3 * size_t(k);
                     o[0] = make_float4(p0[0], p0[1], p0[2], fp);
                     o[1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.0f);
                     o[2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f);
@@ -413,7 +426,8 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             return uint32_t(std::min(65535.0, std::max(0.0, g)));
         };
         // Collapse: the navigation node of binary interior node N has one slot per grandchild of N, or per child where
-        // that child is a leaf; navigation nodes are the interior nodes at even depth.  They are numbered in the order of
+        // that child is a leaf or a fat leaf; navigation nodes are the interior nodes at even depth that are not fat
+        // leaves.  They are numbered in the order of
         // their binary node index (the reference's numbering keeps a subtree contiguous) when every child index exceeds
         // its parent's, as in every tree a top-down builder emits -- one streaming pass; otherwise depth-first.
         std::vector<uint32_t> wide_id(d->n_nodes, kEmptyRef), order;
@@ -427,6 +441,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
                     forward = false;
                     break;
                 }
+                if (fat[i]) continue;
                 odd[b.first] = odd[b.first + 1] = odd[i] ^ 1;
                 if (!odd[i]) {
                     wide_id[i] = uint32_t(order.size());
@@ -437,7 +452,8 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
                 std::fill(wide_id.begin(), wide_id.end(), kEmptyRef);
                 order.clear();
                 std::vector<uint32_t> stack;
-                if (d->nodes[0].count == 0) stack.push_back(0u);
+                auto leaf_like = [&](uint32_t c) { return d->nodes[c].count != 0u || fat[c]; };
+                if (!leaf_like(0u)) stack.push_back(0u);
                 while (!stack.empty()) {
                     const uint32_t n = stack.back();
                     stack.pop_back();
@@ -447,7 +463,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
                     int ns = 0;
                     for (uint32_t k = 0; k < 2; ++k) {
                         const uint32_t c = d->nodes[n].first + k;
-                        if (d->nodes[c].count) {
+                        if (leaf_like(c)) {
                             slots[ns++] = c;
                         } else {
                             slots[ns++] = d->nodes[c].first;
@@ -455,13 +471,15 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
                         }
                     }
                     for (int k = ns - 1; k >= 0; --k)
-                        if (d->nodes[slots[k]].count == 0) stack.push_back(slots[k]);
+                        if (!leaf_like(slots[k])) stack.push_back(slots[k]);
                 }
             }
         }
         auto ref_of = [&](uint32_t ni) -> uint32_t {
             const pt_bvh_node& b = d->nodes[ni];
-            return b.count ? (kLeafBit | (b.count << kLeafCountShift) | slot_of[ni]) : wide_id[ni];
+            if (b.count) return kLeafBit | (b.count << kLeafCountShift) | slot_of[ni];
+            if (fat[ni]) return kLeafBit | ((d->nodes[b.first].count + d->nodes[b.first + 1].count) << kLeafCountShift) | slot_of[b.first];
+            return wide_id[ni];
         };
         if (int rc = fill_upload<uint4>(
                 s, std::max<size_t>(order.size(), 1), [](size_t u) { return size_t(kWide) * u; }, &dev.qnodes, [&](size_t wi, uint4* w) {
@@ -479,7 +497,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
                     };
                     for (uint32_t k = 0; k < 2; ++k) {
                         const uint32_t c = d->nodes[n].first + k;
-                        if (d->nodes[c].count) {
+                        if (d->nodes[c].count || fat[c]) {
                             put(c);
                         } else {
                             put(d->nodes[c].first);

@@ -10,6 +10,18 @@ namespace ptd {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLeafCountShift = 27;
 constexpr uint32_t kLeafFirstMask = (1u << kLeafCountShift) - 1u;
+// Fat leaves: an interior node of the reference's tree whose two children are leaves with at most this many triangles
+// between them is ONE leaf of the navigation structure (one header -- both children have the same parent box, which is
+// all the exact decision at the end of a query needs -- followed by the triangles of both).  The reference's builder
+// splits down to one or two triangles per leaf, mostly the two halves of a quad with nearly the same box: visiting the
+// pair's node and then both leaves costs a navigation step and a leaf phase more than testing both triangles at once.
+// Trying a triangle the reference's walk would not have reached is harmless: candidates are filtered by the decision on
+// their leaf's parent box when the query ends.
+#ifndef PT_FAT_LEAF_TRIS
+#define PT_FAT_LEAF_TRIS 3
+#endif
+constexpr uint32_t kFatLeafTris = PT_FAT_LEAF_TRIS;
+static_assert(kFatLeafTris <= 15u, "the leaf reference has four bits for the triangle count");
 
 // Shading record of one triangle: exactly one 128-byte line, 8 x float4, everything the shade step needs about the
 // surface it hit (the reference chases Triangle* -> TriangleMesh -> index arrays -> vertex arrays, and Material*,
