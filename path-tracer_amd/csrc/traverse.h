@@ -280,14 +280,14 @@ PTD bool tri_hit(V3 p0, V3 e1, V3 e2, const V3& o, const V3& d, float min_dis, f
 //
 // box_cheap: entry / exit estimates t = ((q_org + q * q_step) - o) / d from one convert and one fused multiply-add per
 // plane, t = q * A + B with the per-ray constants A = q_step / d, B = (q_org - o) / d.  Against the exact value the
-// estimate is off by at most 2^-22 (|q_org - o| + extent) / |d| (roundings of 1/d, A, B and the difference) plus
-// 2^-24 |t|.  The first term is an absolute error on the scale of THAT axis (huge for an axis the ray is nearly
-// parallel to, where the slab is just as wide), so it is folded into B per axis: the plane the ray meets first gets
-// B - pad, the other one B + pad, pad = kCheapPad (|q_org - o| + extent) / |d| -- the slab only ever widens.  The
-// relative term, and the 2^-23 |t| by which the reference's own quotient differs from the exact one, are covered by
-// kCheapRel in cheap_go.
-constexpr float kCheapRel = 0x1p-19f;
-constexpr float kCheapPad = 0x1p-21f;
+// estimate is off by at most 2^-22 S (roundings of 1/d, A, B and the difference) plus 2^-24 |t| (the multiply-add's own
+// rounding), S = (|q_org - o| + extent) / |d| on that axis; the reference's own quotient differs from the exact one by
+// another 2^-23 |t|.  Every plane of an axis lies inside the scene bounds, so |t| <= S there and all of it is below
+// 1.75 * 2^-22 S: an absolute error on the scale of THAT axis (huge for an axis the ray is nearly parallel to, where the
+// slab is just as wide).  It is folded into B per axis: the plane the ray meets first gets B - pad, the other one
+// B + pad, pad = kCheapPad S with kCheapPad = 2^-20 (2.3 times the bound; the 16-bit grid step is 2^-16 of the extent) --
+// every entry estimate is at or below the reference's quotient, every exit estimate at or above it.
+constexpr float kCheapPad = 0x1p-20f;
 // Relative width of the distance window inside which two candidates count as "equally near" for the purpose of
 // deciding whether visit order can matter (ClosestLane in traverse_wave.h); also the margin by which box and triangle
 // distances of the same geometry are assumed to agree.
@@ -332,8 +332,7 @@ PTD BoxC box_cheap(uint32_t cx, uint32_t cy, uint32_t cz, const CheapRay& r) {
 // distance (for a box that ends behind the ray's origin the entry is the larger of its two distances, the scale of the
 // rounding errors of the triangle distances inside the box).
 PTD bool cheap_go(const BoxC& b, float tmin, float far) {
-    const float tfp = __fmaf_rn(fabsf(b.tf), kCheapRel, b.tf);
-    return b.tn <= tfp && b.tn <= far && __fmaf_rn(kNearTie, fabsf(b.tn), tfp) >= tmin;
+    return b.tn <= b.tf && b.tn <= far && __fmaf_rn(kNearTie, fabsf(b.tn), b.tf) >= tmin;
 }
 
 constexpr uint32_t kEmptyRef = 0xffffffffu;  // unused slot of a navigation node
