@@ -169,11 +169,11 @@ def test_astronomically_large_scene_takes_the_plain_division_path():
 
 def test_hand_made_deep_tree_runs_on_the_spilled_stack():
     """A 46-level comb-shaped tree (helpers.comb_scene_and_tree) handed to the backend in place of the builder's: rays
-    along the spine keep up to 44 deferred subtrees on the traversal stack, well past its 24 LDS entries.  Both modes
-    must agree bit for bit on this tree; against the oracle (which builds the reference's tree over the same triangles)
-    the hits agree except where a ray grazes a box face of one of the two trees."""
+    along the spine keep up to 44 deferred subtrees on the traversal stack, well past its LDS rows.  The oracle walks the
+    SAME tree (its test hook for a given node array), so hits, occlusion flags and the first occluder must be the
+    oracle's bit for bit in both modes -- the spilled part of the stack included."""
     sd, nodes, ids = helpers.comb_scene_and_tree(44)
-    g, o = api.Scene(sd, bvh=(nodes, ids)), orc.Scene(sd)
+    g, o = api.Scene(sd, bvh=(nodes, ids)), orc.Scene(sd, bvh=(nodes, ids))
     rng = np.random.default_rng(3)
     n = 6000
     rays = np.zeros((n, 8), np.float32)
@@ -187,16 +187,16 @@ def test_hand_made_deep_tree_runs_on_the_spilled_stack():
     rays[:, 7] = np.inf
     rays[n // 2:, 7] = rng.uniform(5.0, 60.0, n - n // 2)
     exact, fast, want = g.intersect(rays, api.TRAVERSE_EXACT), g.intersect(rays, api.TRAVERSE_FAST), o.intersect(rays)
-    assert np.array_equal(fast.view(np.uint32), exact.view(np.uint32))
     assert 0.3 < (want["prim"] >= 0).mean() < 0.999
-    assert helpers.hits_equal(exact, want).mean() > 0.999
-    occ_e, occ_f, occ_w = g.occluded(rays, api.TRAVERSE_EXACT)[0], g.occluded(rays, api.TRAVERSE_FAST)[0], o.occluded(rays)[0]
-    assert np.array_equal(occ_e, occ_f) and (occ_e == occ_w).mean() > 0.999
+    assert helpers.hits_equal(exact, want).all()
+    assert helpers.hits_equal(fast, want).all()
+    (occ_e, first_e), occ_f, (occ_w, first_w) = g.occluded(rays, api.TRAVERSE_EXACT), g.occluded(rays, api.TRAVERSE_FAST)[0], o.occluded(rays)
+    assert np.array_equal(occ_e, occ_w) and np.array_equal(first_e, first_w) and np.array_equal(occ_f, occ_w)
     film, st = g.render(0, 8, traversal=api.TRAVERSE_FAST)
     film_e, st_e = g.render(0, 8, traversal=api.TRAVERSE_EXACT)
     want_film, _ = o.render(0, 8)
     assert (st["closest_rays"], st["any_rays"]) == (st_e["closest_rays"], st_e["any_rays"])
-    assert helpers.rel_mse(api.film_to_image(film), orc.film_to_image(want_film)) < 1e-4
+    assert helpers.rel_mse(api.film_to_image(film), orc.film_to_image(want_film)) < 1e-5
     g.close()
 
 
