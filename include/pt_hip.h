@@ -259,6 +259,14 @@ int pt_hip_sobol(pt_hip_scene* scene, const int32_t* pixel_xy, const uint32_t* s
  * reports how many quotients differ (must be 0). */
 int pt_hip_selftest_division(uint64_t pairs, uint64_t seed, uint64_t* mismatches);
 
+/* No counterpart in the reference (test hooks).  The two bare functions of the traversal for explicit operand pairs, exactly
+ * as the kernels evaluate them: AABB::intersect (src/aabb.cpp:6-35; boxes6 = lo.xyz, hi.xyz per pair; accepted[i] = 1 when
+ * the reference would accept box i for ray i with the ray's own near and far end) and Triangle::intersect
+ * (src/shape.cpp:50-89; tri9 = the three corners per pair; tuv = t, u, v of accepted hits, zeros otherwise).  Host
+ * pointers.  Need pt_hip_init. */
+int pt_hip_probe_box(const float* boxes6, const pt_ray* rays, size_t n, uint8_t* accepted);
+int pt_hip_probe_triangle(const float* tri9, const pt_ray* rays, size_t n, uint8_t* hit, float* tuv);
+
 #ifdef __cplusplus
 }
 #endif

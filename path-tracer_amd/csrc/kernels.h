@@ -894,6 +894,38 @@ __global__ void k_sobol(DevScene sc, const uint32_t* frame_tab, const int32_t* x
     out[i] = smp.value(int(dim[i]));
 }
 
+// ------------------------------------------------------------------------------------------------ bare-function probes
+
+// AABB::intersect (src/aabb.cpp:6-35) for explicit (box, ray) pairs, through the same routines and the same choice between
+// the short division and the plain one as the reference-order traversal makes (closest_exact): accepted = the slabs
+// overlap, the x/y entry lies before the ray's far end and the exit behind its near end.
+__global__ void k_probe_box(DevScene sc, const float* boxes6, const float4* rays, uint32_t n, uint8_t* accepted) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
+    const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
+    const RayPre pre = make_pre(sc, ray);
+    const float* b = boxes6 + 6 * size_t(i);
+    const BoxT t = pre.special ? box_decide<true>(b[0], b[1], b[2], b[3], b[4], b[5], pre) : box_decide<false>(b[0], b[1], b[2], b[3], b[4], b[5], pre);
+    accepted[i] = (t.overlap && t.tn < ray.tmax) ? 1 : 0;
+}
+
+// Triangle::intersect (src/shape.cpp:50-89) for explicit (triangle, ray) pairs on the record form the leaf array holds
+// ({p0, p1 - p0, p2 - p0}); tuv receives t, u, v of accepted hits (zeros otherwise).
+__global__ void k_probe_triangle(const float* tri9, const float4* rays, uint32_t n, uint8_t* hit, float* tuv) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 r0 = rays[2 * size_t(i)], r1 = rays[2 * size_t(i) + 1];
+    const float* p = tri9 + 9 * size_t(i);
+    const V3 p0{p[0], p[1], p[2]}, p1{p[3], p[4], p[5]}, p2{p[6], p[7], p[8]};
+    float t = 0.0f, u = 0.0f, v = 0.0f;
+    const bool h = tri_hit(p0, p1 - p0, p2 - p0, V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w, t, u, v);
+    hit[i] = h ? 1 : 0;
+    tuv[3 * size_t(i) + 0] = h ? t : 0.0f;
+    tuv[3 * size_t(i) + 1] = h ? u : 0.0f;
+    tuv[3 * size_t(i) + 2] = h ? v : 0.0f;
+}
+
 // ------------------------------------------------------------------------------------------------ division self test
 
 // Feeds pseudo-random and adversarial operand pairs (mantissas of all ones, powers of two and their neighbours, slab-

@@ -1049,6 +1049,22 @@ int prepare_split(pt_hip_scene* s, uint32_t rank, uint32_t count, uint32_t tiles
     return PT_OK;
 }
 
+// device copies of the host arrays of a probe call, released when the call ends
+struct ProbeBuffers {
+    std::vector<void*> mem;
+    ~ProbeBuffers() {
+        for (void* p : mem) (void)hipFree(p);
+    }
+    template <typename T>
+    int in(const T* host, size_t count, T** dev) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(dev), std::max<size_t>(count * sizeof(T), 16)));
+        mem.push_back(*dev);
+        if (host) HIP_TRY(hipMemcpy(*dev, host, count * sizeof(T), hipMemcpyHostToDevice));
+        return PT_OK;
+    }
+};
+
+
 }  // namespace
 
 namespace pth {
@@ -1570,6 +1586,47 @@ int pt_hip_selftest_division(uint64_t pairs, uint64_t seed, uint64_t* mismatches
     const int rc = run();
     (void)hipFree(d);
     return rc;
+}
+
+int pt_hip_probe_box(const float* boxes6, const pt_ray* rays, size_t n, uint8_t* accepted) {
+    if (int rc = bind_default()) return rc;
+    if (n == 0) return PT_OK;
+    if (!boxes6 || !rays || !accepted || n > 0x7fffffffull) return fail(PT_ERR_INVALID, "bad argument");
+    ProbeBuffers pb;
+    float* d_box = nullptr;
+    pt_ray* d_ray = nullptr;
+    uint8_t* d_out = nullptr;
+    if (int rc = pb.in(boxes6, 6 * n, &d_box)) return rc;
+    if (int rc = pb.in(rays, n, &d_ray)) return rc;
+    if (int rc = pb.in<uint8_t>(nullptr, n, &d_out)) return rc;
+    DevScene none{};  // only the "every ray takes the plain division" switch of make_pre is read: off
+    hipLaunchKernelGGL(k_probe_box, dim3(blocks(uint32_t(n), 256)), dim3(256), 0, g_stream, none, d_box, reinterpret_cast<const float4*>(d_ray), uint32_t(n),
+                       d_out);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(accepted, d_out, n, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_hip_probe_triangle(const float* tri9, const pt_ray* rays, size_t n, uint8_t* hit, float* tuv) {
+    if (int rc = bind_default()) return rc;
+    if (n == 0) return PT_OK;
+    if (!tri9 || !rays || !hit || !tuv || n > 0x7fffffffull) return fail(PT_ERR_INVALID, "bad argument");
+    ProbeBuffers pb;
+    float *d_tri = nullptr, *d_tuv = nullptr;
+    pt_ray* d_ray = nullptr;
+    uint8_t* d_hit = nullptr;
+    if (int rc = pb.in(tri9, 9 * n, &d_tri)) return rc;
+    if (int rc = pb.in(rays, n, &d_ray)) return rc;
+    if (int rc = pb.in<uint8_t>(nullptr, n, &d_hit)) return rc;
+    if (int rc = pb.in<float>(nullptr, 3 * n, &d_tuv)) return rc;
+    hipLaunchKernelGGL(k_probe_triangle, dim3(blocks(uint32_t(n), 256)), dim3(256), 0, g_stream, d_tri, reinterpret_cast<const float4*>(d_ray), uint32_t(n),
+                       d_hit, d_tuv);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(hit, d_hit, n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tuv, d_tuv, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    return PT_OK;
 }
 
 int pt_hip_sobol(pt_hip_scene* s, const int32_t* pixel_xy, const uint32_t* sample_index, const uint32_t* dim, size_t n, float* out) {

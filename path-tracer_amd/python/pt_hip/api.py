@@ -122,6 +122,8 @@ def hip_lib():
         L.pt_hip_li.argtypes = [C.c_void_p, C.POINTER(RenderParams), c_i32p, c_u32p, C.c_size_t, c_f32p, c_f32p, C.POINTER(Stats)]
         L.pt_hip_sobol.argtypes = [C.c_void_p, c_i32p, c_u32p, c_u32p, C.c_size_t, c_f32p]
         L.pt_hip_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.pt_hip_probe_box.argtypes = [c_f32p, C.c_void_p, C.c_size_t, c_u8p]
+        L.pt_hip_probe_triangle.argtypes = [c_f32p, C.c_void_p, C.c_size_t, c_u8p, c_f32p]
         L.pt_hip_build_bvh.argtypes = [c_f32p, C.c_uint32, c_u32p, C.c_uint32, C.POINTER(C.POINTER(BvhNode)), c_u32p, C.POINTER(c_u32p), c_u32p]
         L.pt_hip_free.argtypes = [C.c_void_p]
         _hip = L
@@ -376,6 +378,24 @@ def selftest_division(pairs, seed=1, device=0):
     bad = C.c_uint64(0)
     _chk(hip_lib().pt_hip_selftest_division(pairs, seed, C.byref(bad)))
     return bad.value
+
+
+def probe_box(boxes6, rays, device=0):
+    """AABB::intersect for explicit (box, ray) pairs as the kernels evaluate it: n x 6 boxes, n x 8 rays -> uint8[n]."""
+    init(device)
+    boxes6, rays = np.ascontiguousarray(boxes6, np.float32), np.ascontiguousarray(rays, np.float32)
+    out = np.zeros(len(rays), np.uint8)
+    _chk(hip_lib().pt_hip_probe_box(_p(boxes6, c_f32p), rays.ctypes.data_as(C.c_void_p), len(rays), _p(out, c_u8p)))
+    return out
+
+
+def probe_triangle(tri9, rays, device=0):
+    """Triangle::intersect for explicit (triangle, ray) pairs: n x 9 corners, n x 8 rays -> (uint8[n], float32[n, 3] t u v)."""
+    init(device)
+    tri9, rays = np.ascontiguousarray(tri9, np.float32), np.ascontiguousarray(rays, np.float32)
+    hit, tuv = np.zeros(len(rays), np.uint8), np.zeros((len(rays), 3), np.float32)
+    _chk(hip_lib().pt_hip_probe_triangle(_p(tri9, c_f32p), rays.ctypes.data_as(C.c_void_p), len(rays), _p(hit, c_u8p), _p(tuv, c_f32p)))
+    return hit, tuv
 
 
 def film_to_image(film):

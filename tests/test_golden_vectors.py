@@ -70,3 +70,26 @@ def test_gpu_matches_the_committed_vectors(want, veach_gpu, veach_sd):
     assert np.array_equal(ps.view(np.uint32), want["li_pixel_sample"].view(np.uint32))
     err = np.abs(rgb - want["li_rgb"]).max(1) / (np.abs(want["li_rgb"]).max(1) + 1e-3)
     assert (err < 1e-3).mean() >= 0.99                                     # device sin / cos / pow differ from libm's by ulps
+
+
+@pytest.mark.gpu
+def test_gpu_bare_functions_match_the_committed_vectors(want):
+    """Triangle::intersect and AABB::intersect on their own (no tree around them), through the probe entry points: the
+    10^4 adversarial pairs each of the committed vectors, bit for bit."""
+    from pt_hip import api, synth
+    soup = synth.random_soup(200, seed=5)                                  # the triangles the vectors were made on
+    corners = soup.verts[soup.vi[want["tri_prim"]] - 1].reshape(-1, 9)
+    hit, tuv = api.probe_triangle(corners, want["tri_rays"])
+    assert np.array_equal(hit, want["tri_hit"])
+    assert np.array_equal(tuv[:, 0].view(np.uint32), want["tri_t"].view(np.uint32))
+    m = want["tri_hit"] == 1
+    assert np.array_equal(tuv[m, 1].view(np.uint32), want["tri_bary"][m, 1].view(np.uint32))
+    assert np.array_equal(tuv[m, 2].view(np.uint32), want["tri_bary"][m, 2].view(np.uint32))
+    at = want["tri_rays"].copy()
+    at[:, 7] = np.where(m, want["tri_t"], 1.0)
+    before = at.copy()
+    before[:, 7] = np.nextafter(at[:, 7], np.float32(0))
+    assert np.array_equal(api.probe_triangle(corners, at)[0], want["tri_hit_far_end_at_t"])
+    assert np.array_equal(api.probe_triangle(corners, before)[0], want["tri_hit_far_end_before_t"])
+    assert np.array_equal(api.probe_box(want["box_boxes"], want["box_rays"]), want["box_hit"])
+
