@@ -233,7 +233,12 @@ struct ClosestLane {
             return true;
         }
         bound = hit.t * (1.0f + 2.0f * kNearTie);
-        return near_tie || (tmax < __builtin_huge_valf() && !(hit.t * (1.0f + kNearTie) < tmax));
+        const bool order_matters = near_tie || (tmax < __builtin_huge_valf() && !(hit.t * (1.0f + kNearTie) < tmax));
+        // A winner at distance zero (a ray that starts on a surface with a near end of zero): the relative window has no
+        // width there, and a replay bounded to 0 would cull the very boxes that hold the winner (the reference enters a
+        // box whose entry distance is BELOW its bound, and 0 < 0 fails).  Replay such a query all the way.
+        if (order_matters && !(bound > hit.t)) bound = kDeferExact;
+        return order_matters;
     }
 };
 

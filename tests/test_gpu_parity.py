@@ -141,6 +141,32 @@ def test_traversal_parity_synthetic_scenes(make):
     g.close()
 
 
+def test_rays_that_start_on_a_surface_hit_it_at_distance_zero():
+    """Origins exactly on triangles (and on the shared planes of coplanar neighbours) with a near end of zero: the
+    reference reports the hit at t = 0.  The ordered mode's distance windows are relative and have no width there; such
+    queries must fall back to the reference order instead of replaying it up to a bound of zero."""
+    sd = synth.library_synth(detail=1, seed=2)
+    o, g = orc.Scene(sd), api.Scene(sd)
+    rng = np.random.default_rng(11)
+    n = 60000
+    v = sd.verts[sd.vi - 1]
+    t = rng.integers(0, len(v), n)
+    w = rng.dirichlet((1, 1, 1), n)
+    w[: n // 4] = np.array([0.5, 0.5, 0.0])                                  # on an edge: two triangles at distance zero
+    org = (v[t] * w[:, :, None]).sum(1)
+    d = rng.normal(size=(n, 3))
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 3:6] = org, d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.where(rng.random(n) < 0.5, np.inf, rng.uniform(0.0, 2.0, n))
+    want = o.intersect(rays)
+    assert ((want["prim"] >= 0) & (want["t"] == 0)).mean() > 0.2
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_EXACT), want).all()
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_FAST), want).all()
+    occ = o.occluded(rays)[0]
+    assert np.array_equal(g.occluded(rays, api.TRAVERSE_EXACT)[0], occ) and np.array_equal(g.occluded(rays, api.TRAVERSE_FAST)[0], occ)
+    g.close()
+
+
 def test_astronomically_large_scene_takes_the_plain_division_path():
     """Coordinates beyond 2^59: the products of the short division could overflow, so every ray of such a scene is routed
     through the IEEE division form of the box test (in the follow-up kernels of the ordered mode).  Same hits as the

@@ -1,0 +1,61 @@
+"""Scratch: ordered against reference-order traversal on random scenes and rays, bit for bit (hits, t, u, v, occlusion).
+Scenes: triangle soups of several sizes and triangle scales (leaves of one to eight triangles, fat leaves of every mix),
+tessellated boxes, the interior stand-in.  Rays: between random points of the scene bounds (both unbounded and ending
+near surfaces), axis-parallel ones, and rays starting on triangles.  Usage: gpu_fuzz.py <seeds> <rays per scene>"""
+import sys
+sys.path[:0] = ['path-tracer_amd/python', '.']
+import numpy as np
+from pt_hip import api, synth
+
+seeds, n = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+for seed in range(seeds):
+    rng = np.random.default_rng(1000 + seed)
+    kind = seed % 4
+    if kind == 0:
+        sd = synth.random_soup(int(rng.integers(2, 20000)), seed=seed, extent=float(rng.uniform(1, 50)), size=float(rng.uniform(0.02, 3.0)))
+    elif kind == 1:
+        sd = synth.random_soup(int(rng.integers(2, 300)), seed=seed, extent=4.0, size=float(rng.uniform(1.0, 8.0)))   # heavy overlap: big leaves
+    elif kind == 2:
+        sd = synth.library_synth(detail=int(rng.integers(1, 4)), seed=seed)
+    else:
+        sd = synth.bathroom_synth(detail=int(rng.integers(1, 4)), width=64, height=64)
+    g = api.Scene(sd)
+    v = sd.verts[sd.vi - 1]                                      # T x 3 x 3
+    lo, hi = sd.verts.min(0), sd.verts.max(0)
+    ext = hi - lo
+    a = lo - 0.2 * ext + rng.random((n, 3)) * 1.4 * ext
+    b = lo - 0.2 * ext + rng.random((n, 3)) * 1.4 * ext
+    on = rng.random(n) < 0.4                                     # start on a random triangle, offset along nothing: grazing starts
+    t = rng.integers(0, len(v), n)
+    w = rng.dirichlet((1, 1, 1), n)
+    p = (v[t] * w[:, :, None]).sum(1)
+    a[on] = p[on]
+    to = rng.random(n) < 0.4                                     # aim at a random point of a random triangle
+    t2 = rng.integers(0, len(v), n)
+    w2 = rng.dirichlet((1, 1, 1), n)
+    b[to] = (v[t2] * w2[:, :, None]).sum(1)[to]
+    snap = rng.random(n) < 0.15                                  # coordinates on a coarse grid: origins and targets on box and triangle planes
+    a[snap] = np.round(a[snap] * 8) / 8
+    b[snap] = np.round(b[snap] * 8) / 8
+    d = b - a
+    ax = rng.random(n) < 0.05                                    # axis-parallel: zero components
+    d[ax] *= (rng.random((ax.sum(), 3)) < 0.5)
+    d[(np.abs(d) < 1e-30).all(1)] = (0.0, 0.0, 1.0)
+    dist = np.linalg.norm(d, axis=1)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 3:6] = a, d / dist[:, None]
+    rays[:, 6] = np.where(rng.random(n) < 0.5, 0.0, 1e-4)
+    rays[:, 7] = np.where(rng.random(n) < 0.5, np.inf, dist * np.where(rng.random(n) < 0.5, 1.0, rng.uniform(0.3, 1.5, n)))
+    e, f = g.intersect(rays, api.TRAVERSE_EXACT), g.intersect(rays, api.TRAVERSE_FAST)
+    same = np.array_equal(e.view(np.uint32), f.view(np.uint32))
+    oe, of = g.occluded(rays, api.TRAVERSE_EXACT)[0], g.occluded(rays, api.TRAVERSE_FAST)[0]
+    same_o = np.array_equal(oe, of)
+    print("seed", seed, "kind", kind, "tris", sd.n_tris, "hit rate %.2f" % (e["prim"] >= 0).mean(), "occluded %.2f" % oe.mean(), "closest", same, "any", same_o, flush=True)
+    if not (same and same_o):
+        bad += 1
+        diff = np.nonzero((e.view(np.uint32).reshape(n, -1) != f.view(np.uint32).reshape(n, -1)).any(1))[0]
+        print("  differing closest:", len(diff), diff[:5], e[diff[:3]], f[diff[:3]], rays[diff[:3]], "any:", np.nonzero(oe != of)[0][:5])
+    g.close()
+print("scenes with differences:", bad)
+sys.exit(1 if bad else 0)
