@@ -127,7 +127,11 @@ typedef struct pt_hit {
  * zero, tiny, huge or non-finite direction component are traced in the reference's order from the start, so that the
  * reported triangle, t, u and v are the reference's in both modes; occlusion queries are order-independent by
  * construction.  For occluded rays FAST reports first_prim = -2 (the "first accepted triangle" is a property of the
- * reference's visit order). */
+ * reference's visit order).  The ordered traversal culls by distance and therefore relies on a triangle's computed distance
+ * lying where the triangle lies (within the 2^-13 window of its boxes' entry distances).  Needle-shaped and collapsed
+ * triangles (|e1 x e2| < 2^-10 |e1| |e2|, large enough to pass the reference's |det| >= 1e-5 test) break that -- the
+ * reference "hits" them at distances unrelated to their position -- so a scene that holds any is traversed in reference
+ * order whatever mode is asked for (first_prim is then the reference's). */
 enum { PT_TRAVERSE_EXACT = 0, PT_TRAVERSE_FAST = 1 };
 
 /* Integrators (src/integrator.cpp): MIS path tracer :45-141, shading normal :20-31, base colour :33-43. */

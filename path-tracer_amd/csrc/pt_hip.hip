@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -158,6 +159,10 @@ struct pt_hip_scene {
     uint32_t sob_m = 0;
     uint32_t depth = 0;
     uint32_t width = 0, height = 0;
+    // The mesh holds needle-shaped or collapsed triangles for which Triangle::intersect returns distances that have little
+    // to do with where the triangle lies (see unreliable_triangle): the ordered traversal's distance culling cannot follow
+    // the reference there, so every query on this scene runs in reference order, whatever mode the caller asks for.
+    bool reference_order_only = false;
     Workspace ws;
     EventPool events;
     int device = -1;                  // the GPU this handle lives on
@@ -333,6 +338,20 @@ struct PhaseClock {
     }
 };
 
+// Moeller-Trumbore (src/shape.cpp:50-89) divides by det = e1 . (d x e2), of magnitude |e1 x e2| cos(angle to the normal).
+// For a needle or collapsed triangle, |e1 x e2| below 2^-10 |e1| |e2|, the rounding noise of that expression (about
+// 2^-20 |e1| |e2|) is a sizeable part of it or all of it: the distance it returns is off by far more than the 2^-13 window
+// the ordered traversal works with, up to "hits" at distance zero for rays that pass the triangle's box anywhere.  Such a
+// triangle matters only if det can pass the reference's |det| >= 1e-5 test at all.
+bool unreliable_triangle(const float* e1, const float* e2) {
+    const double cx = double(e1[1]) * e2[2] - double(e1[2]) * e2[1], cy = double(e1[2]) * e2[0] - double(e1[0]) * e2[2],
+                 cz = double(e1[0]) * e2[1] - double(e1[1]) * e2[0];
+    const double area2 = std::sqrt(cx * cx + cy * cy + cz * cz);
+    const double scale = std::sqrt((double(e1[0]) * e1[0] + double(e1[1]) * e1[1] + double(e1[2]) * e1[2]) *
+                                   (double(e2[0]) * e2[0] + double(e2[1]) * e2[1] + double(e2[2]) * e2[2]));
+    return area2 < 0x1p-10 * scale && area2 + 0x1p-19 * scale >= 1e-5;
+}
+
 int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     DevScene& dev = s->dev;
     PhaseClock clk;
@@ -375,6 +394,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             }))
         return rc;
     // leaf array: unit = node (interior nodes contribute nothing)
+    std::atomic<uint32_t> unreliable{0};
     if (int rc = fill_upload<float4>(
             s, d->n_nodes, [&](size_t u) { return 3 * size_t(slot_of[u]); }, &dev.tris, [&](size_t i, float4* h) {
                 const pt_bvh_node& b = d->nodes[i];
@@ -400,9 +420,13 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
                     o[0] = make_float4(p0[0], p0[1], p0[2], fp);
                     o[1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.0f);
                     o[2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f);
+                    if (unreliable_triangle(&o[1].x, &o[2].x)) unreliable.fetch_add(1u, std::memory_order_relaxed);
                 }
             }))
         return rc;
+    s->reference_order_only = unreliable.load() != 0u;
+    if (clk.on && s->reference_order_only)
+        std::fprintf(stderr, "pt_hip_scene_create: %u needle-shaped or collapsed triangles: every query runs in reference order\n", unreliable.load());
     clk.lap("binary nodes + leaf array");
     // navigation nodes of the ordered traversal: 4-wide, 64 bytes each, slot boxes on a 16-bit grid over the root box,
     // rounded outwards (box_cheap in traverse.h)
@@ -958,6 +982,7 @@ int batch_fetch_reserve(pt_hip_scene* s, uint32_t n_shards) {
 int launch_intersect(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_hit* d_hits, int mode, uint32_t* fetch = nullptr) {
     const float4* rays = reinterpret_cast<const float4*>(d_rays);
     float4* hits = reinterpret_cast<float4*>(d_hits);
+    if (s->reference_order_only) mode = PT_TRAVERSE_EXACT;
     if (mode == PT_TRAVERSE_FAST) {
         const uint32_t n_shards = blocks(uint32_t(n), kShard);
         if (!fetch) {
@@ -981,6 +1006,7 @@ int launch_intersect(pt_hip_scene* s, const pt_ray* d_rays, size_t n, pt_hit* d_
 
 int launch_occluded(pt_hip_scene* s, const pt_ray* d_rays, size_t n, uint8_t* d_occ, int32_t* d_first, int mode) {
     const float4* rays = reinterpret_cast<const float4*>(d_rays);
+    if (s->reference_order_only) mode = PT_TRAVERSE_EXACT;
     if (mode == PT_TRAVERSE_FAST) {
         const uint32_t n_shards = blocks(uint32_t(n), kShard);
         if (int rc = batch_fetch_reserve(s, n_shards)) return rc;
@@ -1364,7 +1390,7 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         pa.tile_list = split ? s->tile_list : nullptr;
         pa.tile_pos = split ? s->tile_pos : nullptr;
         pa.integrator = p.integrator;
-        pa.traversal = p.traversal;
+        pa.traversal = s->reference_order_only ? int32_t(PT_TRAVERSE_EXACT) : p.traversal;
         pa.max_bounce = p.max_bounce;
         if (int rc = launch_generate(s, pa, tm, count)) return rc;
         if (st) {
@@ -1535,7 +1561,7 @@ int pt_hip_li(pt_hip_scene* s, const pt_render_params* params, const int32_t* pi
         pa.spp_pass = 1;
         pa.n_slots = uint32_t(n);
         pa.integrator = p.integrator;
-        pa.traversal = p.traversal;
+        pa.traversal = s->reference_order_only ? int32_t(PT_TRAVERSE_EXACT) : p.traversal;
         pa.max_bounce = p.max_bounce;
         pa.list_xy = d_xy;
         pa.list_frame = d_fl;

@@ -343,12 +343,13 @@ constexpr int kWide = 4;                      // slots per navigation node
 constexpr uint32_t kLeafUntested = 1u;
 
 // The reference's decision on the parent box of the leaf at `slot`, with the ray's own far end as the bound (the bound
-// the reference holds when it pops the parent is never larger).  entry = the x/y entry distance it compared.
+// the reference holds when it pops the parent is never larger).  entry = the distance at which the ray enters the box.
 PTD bool leaf_parent_accepts(const DevScene& sc, uint32_t slot, const RayPre& pre, float tmax, float& entry) {
     const float4 h0 = sc.tris[3 * size_t(slot)], h1 = sc.tris[3 * size_t(slot) + 1];
     const BoxT b = box_decide<false>(h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, pre);
     const bool untested = (as_u(h1.z) & kLeafUntested) != 0u;
-    entry = untested ? -__builtin_huge_valf() : b.tn;
+    // the entry over all three slabs: what a replay in reference order bounded by distance (closest_exact_t) culls with
+    entry = untested ? -__builtin_huge_valf() : b.order;
     return untested || (b.overlap && b.tn < tmax);
 }
 

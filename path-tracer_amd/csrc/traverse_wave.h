@@ -130,14 +130,20 @@ struct ClosestLane {
         hit = HitD{-1, 0.0f, 0.0f, 0.0f};
         cur = sc.wide_root;
     }
+    // Boxes are culled against the acceptance bound widened by kNearTie once more: a triangle's computed distance may lie
+    // before the entry distance of the (flat) box around it by rounding, and at the ray's far end there is no other
+    // margin (a ray that ends on a surface it grazes: the plane distance of the box can come out a few ulps beyond the
+    // far end while the triangle's distance is accepted).
+    PTD float cull_bound() const { return window * (1.0f + kNearTie); }
     // the nearest deferred subtree that can still hold a candidate
     PTD void next(DistStack& st) {
         cur = kDone;
+        const float far = cull_bound();
         while (!st.empty()) {
             uint32_t ref;
             float entry;
             st.pop(ref, entry);
-            if (entry <= window) {
+            if (entry <= far) {
                 cur = ref;
                 break;
             }
@@ -151,13 +157,13 @@ struct ClosestLane {
         const uint4* w = sc.qnodes + kWide * size_t(cur);
         wc.node();
         const uint4 c0 = w[0], c1 = w[1], c2 = w[2], c3 = w[3];
-        const float inf = __builtin_huge_valf();
+        const float inf = __builtin_huge_valf(), far = cull_bound();
         const BoxC b0 = box_cheap(c0.x, c0.y, c0.z, cr), b1 = box_cheap(c1.x, c1.y, c1.z, cr);
         const BoxC b2 = box_cheap(c2.x, c2.y, c2.z, cr), b3 = box_cheap(c3.x, c3.y, c3.z, cr);
-        float k0 = (bool(c0.w != kEmptyRef) & cheap_go(b0, tmin, window)) ? b0.tn : inf;
-        float k1 = (bool(c1.w != kEmptyRef) & cheap_go(b1, tmin, window)) ? b1.tn : inf;
-        float k2 = (bool(c2.w != kEmptyRef) & cheap_go(b2, tmin, window)) ? b2.tn : inf;
-        float k3 = (bool(c3.w != kEmptyRef) & cheap_go(b3, tmin, window)) ? b3.tn : inf;
+        float k0 = (bool(c0.w != kEmptyRef) & cheap_go(b0, tmin, far)) ? b0.tn : inf;
+        float k1 = (bool(c1.w != kEmptyRef) & cheap_go(b1, tmin, far)) ? b1.tn : inf;
+        float k2 = (bool(c2.w != kEmptyRef) & cheap_go(b2, tmin, far)) ? b2.tn : inf;
+        float k3 = (bool(c3.w != kEmptyRef) & cheap_go(b3, tmin, far)) ? b3.tn : inf;
         uint32_t r0 = c0.w, r1 = c1.w, r2 = c2.w, r3 = c3.w;
         auto order = [](float& ka, uint32_t& ra, float& kb, uint32_t& rb) {  // afterwards ka <= kb
             const bool sw = kb < ka;
@@ -216,10 +222,12 @@ struct ClosestLane {
     // Called once when the walk has ended.  Returns true when the query has to be repeated in reference order, `bound` =
     // how far (kDeferExact = all the way):
     //  - the reference does not accept the parent box of the winner's leaf, so it never sees the winner: full query;
-    //  - it enters that box beyond the window behind the winner: every bound the reference compares with an ancestor of the
-    //    leaf is another candidate's distance or the ray's far end, all beyond the window (else near_tie below), and the
-    //    ancestors' entry distances are at most the parent's -- so a parent entered within the window makes sure that none
-    //    of them is culled by such a bound; otherwise only the full query is safe;
+    //  - it enters that box beyond the window behind the winner (in any of the three slabs: a grazing ray's triangle
+    //    distance can lie well before the plane distance of the flat box around it): every bound the reference compares
+    //    with an ancestor of the leaf is another candidate's distance or the ray's far end, all beyond the window (else
+    //    near_tie below), and the ancestors' entry distances are at most the parent's -- so a parent entered within the
+    //    window makes sure that none of them is culled by such a bound, nor by the bounded replay; otherwise only the
+    //    full query is safe;
     //  - two candidates, or the winner and the ray's far end, within the window of each other: the visit order decides.
     template <class C>
     PTD bool settle(const DevScene& sc, float& bound, C& wc) {

@@ -167,6 +167,67 @@ def test_rays_that_start_on_a_surface_hit_it_at_distance_zero():
     g.close()
 
 
+def test_grazing_rays_that_end_on_a_flat_scene():
+    """Every triangle in the plane z = 0.25 (every box is flat, overlapping triangles at equal distances) and rays a few
+    millimetres above it that end exactly where they reach a triangle: the distance of the triangle test and the plane
+    distance of the flat boxes around it differ by rounding, on either side of the ray's far end.  The reference compares
+    only the x/y entry of a box with its bound; the ordered mode culls by all three slabs and needs its margin there."""
+    sd = synth.random_soup(220, seed=25, extent=4.0, size=6.0)
+    sd.light_infos = []
+    sd.verts = np.ascontiguousarray(sd.verts, np.float32).copy()
+    sd.verts[:, 2] = np.float32(0.25)
+    o, g = orc.Scene(sd), api.Scene(sd)
+    rng = np.random.default_rng(7)
+    n = 150000
+    v = sd.verts[sd.vi - 1].astype(np.float64)
+    w = rng.dirichlet((1, 1, 1), n)
+    target = (v[rng.integers(0, len(v), n)] * w[:, :, None]).sum(1)
+    org = target + rng.uniform(-12, 12, (n, 3))
+    org[:, 2] = 0.25 + rng.uniform(-0.012, 0.012, n)
+    d = target - org
+    dist = np.linalg.norm(d, axis=1)
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 3:6] = org, d / dist[:, None]
+    rays[:, 7] = np.where(rng.random(n) < 0.8, dist, np.inf)
+    want = o.intersect(rays)
+    assert 0.2 < (want["prim"] >= 0).mean() < 0.999
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_EXACT), want).all()
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_FAST), want).all()
+    occ = o.occluded(rays)[0]
+    assert np.array_equal(g.occluded(rays, api.TRAVERSE_EXACT)[0], occ) and np.array_equal(g.occluded(rays, api.TRAVERSE_FAST)[0], occ)
+    g.close()
+
+
+def test_needle_and_collapsed_triangles_switch_the_scene_to_reference_order():
+    """Large triangles collapsed to segments: for rays that start next to one, the reference's triangle test "hits" it at
+    distances that have nothing to do with where it lies (its determinant is rounding noise above the 1e-5 threshold).
+    No distance-ordered walk can follow that; a scene with such triangles is traversed in reference order in both modes
+    (the ordered mode then reports the reference's first occluder too)."""
+    sd = synth.random_soup(160, seed=69, extent=4.0, size=7.0)
+    sd.light_infos = []
+    rng = np.random.default_rng(3)
+    k = rng.integers(0, sd.n_tris, 16)
+    sd.vi = sd.vi.copy()
+    sd.vi[k, 2] = sd.vi[k, 1]
+    o, g = orc.Scene(sd), api.Scene(sd)
+    n = 100000
+    v = sd.verts[sd.vi - 1].astype(np.float64)
+    w = rng.dirichlet((1, 1, 1), n)
+    org = (v[k[rng.integers(0, len(k), n)]] * w[:, :, None]).sum(1)                 # on the collapsed triangles
+    d = rng.normal(size=(n, 3))
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0:3], rays[:, 3:6] = org, d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 7] = np.inf
+    want = o.intersect(rays)
+    assert ((want["prim"] >= 0) & np.isin(want["prim"], k)).sum() > 20              # the noise hits are there
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_EXACT), want).all()
+    assert helpers.hits_equal(g.intersect(rays, api.TRAVERSE_FAST), want).all()
+    occ, first = o.occluded(rays)
+    g_occ, g_first = g.occluded(rays, api.TRAVERSE_FAST)
+    assert np.array_equal(g_occ, occ) and np.array_equal(g_first, first)
+    g.close()
+
+
 def test_astronomically_large_scene_takes_the_plain_division_path():
     """Coordinates beyond 2^59: the products of the short division could overflow, so every ray of such a scene is routed
     through the IEEE division form of the box test (in the follow-up kernels of the ordered mode).  Same hits as the

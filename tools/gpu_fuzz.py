@@ -9,7 +9,8 @@ from pt_hip import api, synth
 
 seeds, n = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
-for seed in range(seeds):
+only = [int(x) for x in sys.argv[3:]]
+for seed in (only or range(seeds)):
     rng = np.random.default_rng(1000 + seed)
     kind = seed % 4
     if kind == 0:
@@ -20,10 +21,28 @@ for seed in range(seeds):
         sd = synth.library_synth(detail=int(rng.integers(1, 4)), seed=seed)
     else:
         sd = synth.bathroom_synth(detail=int(rng.integers(1, 4)), width=64, height=64)
+    # geometry variations on top (light_infos are dropped: only batched queries are made, and degenerate emitters are refused)
+    twist = int(rng.integers(0, 6))
+    sd.light_infos = []
+    sd.verts = np.ascontiguousarray(sd.verts, np.float32).copy()
+    if twist == 1:                                               # every triangle twice: exact distance ties everywhere
+        for k in ("vi", "ni", "ti", "mat_id"):
+            setattr(sd, k, np.concatenate([getattr(sd, k), getattr(sd, k)]))
+    elif twist == 2:                                             # a tiny scene
+        sd.verts *= np.float32(1e-5)
+    elif twist == 3:                                             # far from the origin: coordinates with few bits left for detail
+        sd.verts += np.float32(3000.0)
+    elif twist == 4:                                             # flattened onto a plane: every box is flat in z
+        sd.verts[:, 2] = np.float32(0.25)
+    elif twist == 5:                                             # some triangles collapsed to segments and points
+        k = rng.integers(0, sd.n_tris, max(1, sd.n_tris // 10))
+        sd.vi = sd.vi.copy()
+        sd.vi[k, 2] = sd.vi[k, 1]
+        sd.vi[k[::2], 1] = sd.vi[k[::2], 0]
     g = api.Scene(sd)
     v = sd.verts[sd.vi - 1]                                      # T x 3 x 3
     lo, hi = sd.verts.min(0), sd.verts.max(0)
-    ext = hi - lo
+    ext = np.maximum(hi - lo, 1e-3 * np.abs(hi - lo).max())
     a = lo - 0.2 * ext + rng.random((n, 3)) * 1.4 * ext
     b = lo - 0.2 * ext + rng.random((n, 3)) * 1.4 * ext
     on = rng.random(n) < 0.4                                     # start on a random triangle, offset along nothing: grazing starts
@@ -36,8 +55,9 @@ for seed in range(seeds):
     w2 = rng.dirichlet((1, 1, 1), n)
     b[to] = (v[t2] * w2[:, :, None]).sum(1)[to]
     snap = rng.random(n) < 0.15                                  # coordinates on a coarse grid: origins and targets on box and triangle planes
-    a[snap] = np.round(a[snap] * 8) / 8
-    b[snap] = np.round(b[snap] * 8) / 8
+    unit = float(2.0 ** np.round(np.log2(ext.max() / 32)))       # a power of two: grid coordinates are exact
+    a[snap] = np.round(a[snap] / unit) * unit
+    b[snap] = np.round(b[snap] / unit) * unit
     d = b - a
     ax = rng.random(n) < 0.05                                    # axis-parallel: zero components
     d[ax] *= (rng.random((ax.sum(), 3)) < 0.5)
@@ -45,17 +65,23 @@ for seed in range(seeds):
     dist = np.linalg.norm(d, axis=1)
     rays = np.zeros((n, 8), np.float32)
     rays[:, 0:3], rays[:, 3:6] = a, d / dist[:, None]
-    rays[:, 6] = np.where(rng.random(n) < 0.5, 0.0, 1e-4)
+    rays[:, 6] = np.where(rng.random(n) < 0.5, 0.0, 1e-4 * ext.max() / 4)
     rays[:, 7] = np.where(rng.random(n) < 0.5, np.inf, dist * np.where(rng.random(n) < 0.5, 1.0, rng.uniform(0.3, 1.5, n)))
     e, f = g.intersect(rays, api.TRAVERSE_EXACT), g.intersect(rays, api.TRAVERSE_FAST)
     same = np.array_equal(e.view(np.uint32), f.view(np.uint32))
     oe, of = g.occluded(rays, api.TRAVERSE_EXACT)[0], g.occluded(rays, api.TRAVERSE_FAST)[0]
     same_o = np.array_equal(oe, of)
-    print("seed", seed, "kind", kind, "tris", sd.n_tris, "hit rate %.2f" % (e["prim"] >= 0).mean(), "occluded %.2f" % oe.mean(), "closest", same, "any", same_o, flush=True)
+    print("seed", seed, "kind", kind, "twist", twist, "tris", sd.n_tris, "hit rate %.2f" % (e["prim"] >= 0).mean(), "occluded %.2f" % oe.mean(), "closest", same, "any", same_o, flush=True)
     if not (same and same_o):
         bad += 1
         diff = np.nonzero((e.view(np.uint32).reshape(n, -1) != f.view(np.uint32).reshape(n, -1)).any(1))[0]
-        print("  differing closest:", len(diff), diff[:5], e[diff[:3]], f[diff[:3]], rays[diff[:3]], "any:", np.nonzero(oe != of)[0][:5])
+        print("  differing closest:", len(diff), diff[:5], "any:", np.nonzero(oe != of)[0][:5])
+        np.set_printoptions(precision=9, linewidth=220)
+        corners = sd.verts[sd.vi - 1].reshape(-1, 9)
+        for i in diff[:4]:
+            hit, tuv = api.probe_triangle(corners, np.repeat(rays[i:i + 1], len(corners), 0))
+            print("   ray", rays[i], "\n     reference order", e[i], "ordered", f[i], "ordered, alone", g.intersect(rays[i:i + 1].copy(), api.TRAVERSE_FAST)[0],
+                  "\n     triangles accepted on their own:", np.nonzero(hit)[0], tuv[hit == 1][:, 0])
     g.close()
 print("scenes with differences:", bad)
 sys.exit(1 if bad else 0)
