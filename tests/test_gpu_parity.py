@@ -346,6 +346,30 @@ def test_per_sample_radiance_matches_oracle(veach_gpu, veach_oracle, veach_sd):
         assert np.isfinite(got).all() and (got >= 0).all()
 
 
+@pytest.mark.parametrize("make", [lambda: synth.library_synth(detail=1, width=96, height=64), lambda: synth.bathroom_synth(detail=2, width=64, height=64),
+                                  lambda: synth.random_soup(3000, seed=3, width=80, height=60), synth.textured_room])
+def test_both_traversal_modes_give_the_same_samples_bit_for_bit(make):
+    """The two modes differ only in how the tree is walked: with identical hits and occlusion flags every sample takes
+    the same path and adds the same terms in the same order, so the radiance of every (pixel, sample) pair must agree in
+    every bit, and so must the ray counts of a render.  (Films agree only up to the order of atomic additions.)"""
+    sd = make()
+    g = api.Scene(sd)
+    spp = 8
+    ys, xs = np.mgrid[0:sd.height, 0:sd.width]
+    pix = np.repeat(np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32), spp, 0)
+    smp = np.tile(np.arange(spp, dtype=np.uint32), sd.width * sd.height)
+    le, pe, _ = g.li(pix, smp, traversal=api.TRAVERSE_EXACT)
+    lf, pf, _ = g.li(pix, smp, traversal=api.TRAVERSE_FAST)
+    assert np.array_equal(pe.view(np.uint32), pf.view(np.uint32))
+    assert np.array_equal(le.view(np.uint32), lf.view(np.uint32))
+    assert np.isfinite(le).all() and le.max() > 0
+    fe, se = g.render(0, spp, traversal=api.TRAVERSE_EXACT)
+    ff, sf = g.render(0, spp, traversal=api.TRAVERSE_FAST, samples_per_pass=3)
+    assert (se["closest_rays"], se["any_rays"]) == (sf["closest_rays"], sf["any_rays"])
+    assert np.allclose(fe, ff, rtol=1e-5, atol=1e-6)
+    g.close()
+
+
 def test_path_traced_image_matches_oracle(veach_gpu, veach_oracle):
     """Converged-image criterion at equal sample sets: relMSE between the GPU film and the oracle film at 16 spp
     (same Sobol' points, so the noise cancels) must stay below 1e-5; the ray counts agree to 0.01%."""
