@@ -131,7 +131,10 @@ typedef struct pt_hit {
  * lying where the triangle lies (within the 2^-13 window of its boxes' entry distances).  Needle-shaped and collapsed
  * triangles (|e1 x e2| < 2^-10 |e1| |e2|, large enough to pass the reference's |det| >= 1e-5 test) break that -- the
  * reference "hits" them at distances unrelated to their position -- so a scene that holds any is traversed in reference
- * order whatever mode is asked for (first_prim is then the reference's). */
+ * order whatever mode is asked for (first_prim is then the reference's).  The same noise, one ray at a time, is what FAST
+ * does not reproduce: a ray within about 1e-4 rad of the plane of a triangle several units long, with |det| just above the
+ * reference's threshold, for which the reference computes a distance far from where the ray meets the triangle (measured:
+ * under one in a million rays aimed that way on purpose, none in ordinary rays); EXACT follows the reference there too. */
 enum { PT_TRAVERSE_EXACT = 0, PT_TRAVERSE_FAST = 1 };
 
 /* Integrators (src/integrator.cpp): MIS path tracer :45-141, shading normal :20-31, base colour :33-43. */

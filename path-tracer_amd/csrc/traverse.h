@@ -291,7 +291,10 @@ constexpr float kCheapPad = 0x1p-20f;
 // Relative width of the distance window inside which two candidates count as "equally near" for the purpose of
 // deciding whether visit order can matter (ClosestLane in traverse_wave.h); also the margin by which box and triangle
 // distances of the same geometry are assumed to agree.
-constexpr float kNearTie = 1.0f / 8192.0f;
+#ifndef PT_NEAR_TIE_LOG2
+#define PT_NEAR_TIE_LOG2 13
+#endif
+constexpr float kNearTie = 1.0f / float(1u << PT_NEAR_TIE_LOG2);
 
 // per-ray constants of box_cheap
 struct CheapRay {

@@ -7,6 +7,8 @@ sys.path[:0] = ['path-tracer_amd/python', '.']
 import numpy as np
 from pt_hip import api, synth
 
+import os
+GRAZE = os.environ.get("FUZZ_GRAZE") == "1"
 seeds, n = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 only = [int(x) for x in sys.argv[3:]]
@@ -59,6 +61,25 @@ for seed in (only or range(seeds)):
     a[snap] = np.round(a[snap] / unit) * unit
     b[snap] = np.round(b[snap] / unit) * unit
     d = b - a
+    graze = rng.random(n) < (0.6 if GRAZE else 0.0)   # towards a point of a triangle, nearly in its plane
+    if graze.any():
+        tg = rng.integers(0, len(v), n)
+        wg = rng.dirichlet((1, 1, 1), n)
+        wg[rng.random(n) < 0.3] = np.array([0.5, 0.5, 0.0])                       # on an edge (a quad's diagonal among them)
+        pt = (v[tg] * wg[:, :, None]).sum(1)
+        e1, e2 = v[tg, 1] - v[tg, 0], v[tg, 2] - v[tg, 0]
+        nrm = np.cross(e1, e2)
+        nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+        ang = rng.uniform(0, 2 * np.pi, n)
+        u = e1 / np.maximum(np.linalg.norm(e1, axis=1, keepdims=True), 1e-30)
+        w3 = np.cross(nrm, u)
+        inplane = u * np.cos(ang)[:, None] + w3 * np.sin(ang)[:, None]
+        eps = 10.0 ** rng.uniform(-6, -1.5, n) * np.where(rng.random(n) < 0.5, 1, -1)
+        dg = inplane + nrm * eps[:, None]
+        L = rng.uniform(0.05, 1.0, n) * ext.max()
+        a[graze] = (pt - dg * L[:, None])[graze]
+        b[graze] = pt[graze]
+        d = b - a
     ax = rng.random(n) < 0.05                                    # axis-parallel: zero components
     d[ax] *= (rng.random((ax.sum(), 3)) < 0.5)
     d[(np.abs(d) < 1e-30).all(1)] = (0.0, 0.0, 1.0)
