@@ -234,14 +234,18 @@ def main():
             "kernel_ms_per_step": {k: v / a.steps for k, v in kms.items()},
             "kernel_launches_per_step": {k: v / a.steps for k, v in kn.items()},
             "bvh_records_per_ray": bvh,
-            # The traversal kernels are not bound by HBM: the records they gather are served by L2 / Infinity Cache, and the
-            # time goes into VALU issue at partial lane occupancy and into waiting for dependent gathers.  `frac` is therefore
-            # the share of the vector ALU's lane throughput that does useful work (issue share x active lanes); the
-            # algorithmic-bytes figure the contract asks for is kept as `achieved` against the HBM peak, next to the bytes
-            # that really crossed the fabric.
-            "roofline": {"bound": "valu", "kernel": "k_" + dominant,
+            # The traversal kernels are not bound by HBM: the records they gather are served by L2 / Infinity Cache.  Nor do
+            # they fill the vector ALU: a CDNA4 SIMD can issue a wave64 instruction every 2 cycles, and the kernel uses under
+            # half of those slots, at half the lanes, because its waves spend most of their time waiting for the next
+            # dependent gather (`wave_wait_frac`) and six of them per SIMD do not cover that.  `frac` is the share of the
+            # vector ALU's lane throughput that does useful work (issue share x active lanes); the algorithmic-bytes figure
+            # the contract asks for is kept as `achieved` against the HBM peak, next to the bytes that really crossed the
+            # fabric.
+            "roofline": {"bound": "latency", "bound_note": "dependent gathers (one node per step and lane) at 6 waves per SIMD; neither the HBM nor the VALU roof is near",
+                         "kernel": "k_" + dominant,
                          "frac": (valu * lanes) if valu is not None and lanes is not None else None,
-                         "valu_issue_frac": valu, "lane_frac": lanes, "l2_hit_rate": counters.get("l2_hit_rate"),
+                         "valu_issue_frac": valu, "valu_issue_frac_at_one_wave_rate": counters.get("valu_issue_frac_at_one_wave_rate"),
+                         "lane_frac": lanes, "wave_wait_frac": counters.get("wave_wait_frac"), "l2_hit_rate": counters.get("l2_hit_rate"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (fabric requests x 64 B)",
                          "hbm_frac_measured": (traffic / counters["avg_launch_ms"] / 1e-3 / 1e9 / HBM_PEAK_GBS) if traffic and counters.get("avg_launch_ms") else None,
