@@ -70,10 +70,12 @@ struct SegBox {
 struct SegBoxOp {
     __host__ __device__ SegBox operator()(const SegBox& a, const SegBox& c) const {
         if (c.head) return c;
+        // AABB::operator+= (include/pt/aabb.h:40-44) with the running box on the left: std::min / std::max semantics, the
+        // earlier operand stays on a tie -- which is what decides between -0 and +0
         SegBox r;
         for (int k = 0; k < 3; ++k) {
-            r.b.lo[k] = fminf(a.b.lo[k], c.b.lo[k]);
-            r.b.hi[k] = fmaxf(a.b.hi[k], c.b.hi[k]);
+            r.b.lo[k] = (c.b.lo[k] < a.b.lo[k]) ? c.b.lo[k] : a.b.lo[k];
+            r.b.hi[k] = (a.b.hi[k] < c.b.hi[k]) ? c.b.hi[k] : a.b.hi[k];
         }
         r.head = a.head;
         r.pad = 0;
@@ -144,6 +146,16 @@ __global__ void k_gather(uint32_t n, const Box* prim, const uint32_t* ord, const
     fwd[i] = e;
     e.head = (i + 1u == nd.end[o]) ? 1u : 0u;
     bwd[n - 1u - i] = e;
+}
+
+// The box of every node of the current level as the reference computes it (computeAABB, include/pt/bvh.h:87-92): the union
+// of its triangles in the order of the axis-0 index array, the running box on the left of every min / max -- i.e. the
+// axis-0 forward scan at the range's last position.  (k_decide creates children with boxes taken from the split axis'
+// scans; those agree in value but not necessarily in the sign of a zero coordinate.)
+__global__ void k_boxes(uint32_t level_begin, uint32_t level_end, BuildNodes nd, const SegBox* pre0) {
+    const uint32_t x = level_begin + blockIdx.x * kThreads + threadIdx.x;
+    if (x >= level_end) return;
+    if (nd.end[x] > nd.begin[x]) nd.box[x] = pre0[nd.end[x] - 1u].b;
 }
 
 // cost of splitting after position i (left = [begin, i], right = [i + 1, end)): src/bvh.cpp:219-229, bvh.h:98-100
@@ -427,6 +439,7 @@ int pth::build_bvh_on_current(const float* verts, uint32_t n_verts, const uint32
             hipLaunchKernelGGL(k_gather, dim3(grid_for(n)), dim3(kThreads), 0, stream, n, d_prim, d_ord[a], d_owner, nd, d_fwd, d_bwd);
             HIP_TRY(hipcub::DeviceScan::InclusiveScan(d_scan_tmp, tmp_bytes, d_fwd, d_pre[a], SegBoxOp(), int(n), stream));
             HIP_TRY(hipcub::DeviceScan::InclusiveScan(d_scan_tmp, tmp_bytes, d_bwd, d_suf[a], SegBoxOp(), int(n), stream));
+            if (a == 0) hipLaunchKernelGGL(k_boxes, dim3(grid_for(level_end - level_begin)), dim3(kThreads), 0, stream, level_begin, level_end, nd, d_pre[0]);
             hipLaunchKernelGGL(k_cost, dim3(grid_for(n)), dim3(kThreads), 0, stream, n, d_owner, nd, level_begin, d_pre[a], d_suf[a], d_cost);
             HIP_TRY(hipcub::DeviceScan::InclusiveScan(d_scan_tmp, tmp_bytes, d_cost, d_min[a], SegMinOp(), int(n), stream));
         }

@@ -742,6 +742,25 @@ def test_gpu_tree_build_equals_the_host_builder_node_for_node(make, veach_sd):
     assert np.array_equal(nodes.view(np.uint32), want_nodes.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", [1, 17, 59])
+def test_gpu_tree_build_on_coordinates_full_of_ties_and_signed_zeros(seed):
+    """Vertices snapped to a coarse grid: equal centroids (every sort tie), flat and collapsed triangles, equally cheap
+    split candidates, and box coordinates that are -0 in one triangle and +0 in the next.  The reference accumulates a box
+    with the running value on the left of std::min / std::max, in the order of the axis-0 index array, so which zero a box
+    ends up with is part of the tree; the device builder has to reproduce it (it once took the children's boxes from the
+    split axis' scans)."""
+    rng = np.random.default_rng(seed)
+    sd = synth.random_soup(int(rng.integers(2000, 30000)), seed=seed, extent=float(rng.uniform(2, 30)), size=float(rng.uniform(0.3, 3.0)))
+    verts = (np.round(sd.verts * 4) / 4).astype(np.float32)
+    verts[verts == 0] = np.where(rng.random((verts == 0).sum()) < 0.5, np.float32(-0.0), np.float32(0.0))
+    want_nodes, want_ids, want_depth = api.build_bvh(verts, sd.vi)
+    nodes, ids, depth = api.build_bvh_gpu(verts, sd.vi)
+    assert len(nodes) == len(want_nodes) and depth == want_depth
+    assert np.array_equal(ids, want_ids)
+    assert np.array_equal(nodes.view(np.uint32), want_nodes.view(np.uint32))
+    assert np.signbit(want_nodes["hi"][want_nodes["hi"] == 0]).any() and not np.signbit(want_nodes["hi"][want_nodes["hi"] == 0]).all()
+
+
 def test_scene_description_without_a_tree_is_built_on_the_device():
     """pt_hip_scene_create with nodes == NULL builds the reference's tree itself: same hits, same film as with the host
     builder's tree handed over."""
