@@ -143,7 +143,9 @@ enum { PT_INTEGRATOR_PATH = 0, PT_INTEGRATOR_NORMAL = 1, PT_INTEGRATOR_ALBEDO = 
 typedef struct pt_render_params {
     uint32_t spp_begin;        /* first Sobol' sample index (inclusive) */
     uint32_t spp_end;          /* last sample index (exclusive) */
-    uint32_t max_bounce;       /* 32 in the reference (src/integrator.cpp:50); 0 selects 32 */
+    uint32_t max_bounce;       /* 32 in the reference (src/integrator.cpp:50); 0 selects 32.  Specular bounces are not counted
+                                * (src/integrator.cpp:84-87): a chain of mirror reflections is followed however long it is
+                                * (the loop gives up after 2^20 iterations of one pass, where the reference would not return) */
     int32_t  integrator;       /* PT_INTEGRATOR_* */
     int32_t  traversal;        /* PT_TRAVERSE_* */
     uint32_t samples_per_pass; /* samples of every pixel in flight at once; 0 = automatic (up to 537 M paths, 120 GB of queues) */

@@ -825,6 +825,8 @@ int launch_generate(pt_hip_scene* s, const PassArgs& pa, Timer& tm, bool count) 
     return PT_OK;
 }
 
+constexpr uint32_t kMaxIterations = 1u << 20;  // of the bounce loop, per pass
+
 // The bounce loop shared by pt_hip_render_device and pt_hip_li; k_generate has filled path queue 0 and hit list 0.
 //
 // The host never waits for a kernel it needs the result of right away.  After the shade of bounce b it queues a copy of
@@ -866,11 +868,18 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
         }
         return PT_OK;
     };
-    // every loop iteration is one bounce; specular chains do not advance the bounce counter (src/integrator.cpp:84-87),
-    // so bound the loop independently
-    for (uint32_t iter = 0; iter < 8 * pa.max_bounce; ++iter) {
+    // Every loop iteration is one pass of the reference's loop body.  A specular bounce does not advance the bounce counter
+    // (src/integrator.cpp:84-87), so max_bounce does not bound the iterations: a mirror with interpolated normals can
+    // reflect a ray below its own surface, and the path then creeps along a crease for thousands of reflections before
+    // it escapes.  The reference follows it to the end and so does this loop (a few stragglers cost three small launches
+    // per reflection); kMaxIterations only stops a path that never ends, on which the reference would not return.
+    for (uint32_t iter = 0; iter < kMaxIterations; ++iter) {
         if (int rc = consume(true)) return rc;  // the previous bounce's snapshot
         if (finished) break;
+        if (iter != 0 && iter % 256u == 0) {  // long chains: fold the timing events in now instead of keeping three pairs per iteration
+            HIP_TRY(hipStreamSynchronize(g_stream));
+            if (int rc = tm.collect(st)) return rc;
+        }
         const int cur = int(iter & 1u), nxt = cur ^ 1;
         ws.hq.count = ws.hit_count[cur];
         HitQ hq_next = ws.hq;
