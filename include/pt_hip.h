@@ -177,7 +177,7 @@ typedef struct pt_stats {
     double   kernel_ms[PT_MAX_KERNEL_STATS];
     uint64_t kernel_launches[PT_MAX_KERNEL_STATS];
 } pt_stats;
-enum { PT_K_GENERATE = 0, PT_K_EXTEND = 1, PT_K_SHADE = 2, PT_K_SHADOW = 3, PT_K_FILM = 4, PT_K_RETRACE = 5 };
+enum { PT_K_GENERATE = 0, PT_K_EXTEND = 1, PT_K_SHADE = 2, PT_K_SHADOW = 3, PT_K_FILM = 4, PT_K_RETRACE = 5, PT_K_FINISH = 6 };
 
 typedef struct pt_hip_scene pt_hip_scene;
 
@@ -275,6 +275,12 @@ int pt_hip_selftest_division(uint64_t pairs, uint64_t seed, uint64_t* mismatches
  * pointers.  Need pt_hip_init. */
 int pt_hip_probe_box(const float* boxes6, const pt_ray* rays, size_t n, uint8_t* accepted);
 int pt_hip_probe_triangle(const float* tri9, const pt_ray* rays, size_t n, uint8_t* hit, float* tuv);
+
+/* No counterpart in the reference (test hook).  The shading code's sine, cosine and power for explicit operands: the
+ * reference calls the C library's sinf / cosf (include/pt/common.h:103, 111) and powf (include/pt/common.h:108, src/material.cpp:34, 79, 108), the
+ * kernels evaluate them in double and round once.  sin_cos_pow = sin(x[i]), cos(x[i]), x[i]^y[i] per element.  Host
+ * pointers.  Needs pt_hip_init. */
+int pt_hip_probe_math(const float* x, const float* y, size_t n, float* sin_cos_pow);
 
 #ifdef __cplusplus
 }

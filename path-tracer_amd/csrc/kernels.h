@@ -125,8 +125,9 @@ struct PassArgs {
 };
 
 // misc[0] = exact re-traces.  Counting builds only: for kernel class k (0 generate, 1 extend, 2 shadow) the u64 at
-// word 4 + 4k holds the node records fetched and the u64 at word 6 + 4k the triangle records fetched.
-constexpr int kMiscWords = 16;
+// word 4 + 4k holds the node records fetched and the u64 at word 6 + 4k the triangle records fetched.  Words 16..19: the
+// queries of k_finish (two u64).
+constexpr int kMiscWords = 24;
 
 // A ray that a wave-refill kernel handed back, in reference order: the whole query (plain-division rays, kDeferExact), or
 // bounded by `bound` when the ordered pass has already established that the nearest accepted triangle lies before it.
@@ -626,13 +627,133 @@ __global__ __launch_bounds__(kBlock) void k_occluded_fix(DevScene sc, const floa
 
 // ------------------------------------------------------------------------------------------------ shade
 
+// What one pass of the loop body hands on: the continued path (next ray, throughput, sampler position) and the shadow ray
+// with its already-weighted contribution.
+struct ShadeOut {
+    bool cont = false, want_shadow = false;
+    float4 na{}, nb{}, nc{}, sa{}, sb{}, sc4{};
+};
+
 // One iteration of the loop body of PathIntegrator::Li after the intersection (src/integrator.cpp:55-103) plus
-// sampleLd up to the visibility test (src/integrator.cpp:109-141): the shadow ray and its already-weighted
-// contribution go to the shadow queue, the continued path to the next path queue.
+// sampleLd up to the visibility test (src/integrator.cpp:109-141) for one hit: h0 / h1 are its hit-list entry, a / b / c
+// the state of the path that found it, slot its radiance slot (emitted radiance is added there right away).
 //
 // Memory reads are arranged in three dependent levels: (1) the hit-list entry; (2) the path state, the triangle's
 // shading record and the Sobol' window (all addressed from the entry); (3) the record of the light chosen by the first
 // Sobol' value.
+PTD void shade_hit(const DevScene& sc, const PassArgs& pa, const float4 h0, const float4 h1, const float4 a, const float4 b, const float4 c,
+                   const uint32_t slot, float4* lbuf, ShadeOut& o) {
+    const uint32_t prim = as_u(h0.y);
+    const uint32_t pix = as_u(h1.x), meta = as_u(h1.y);
+    const uint32_t frame = meta >> 16;
+    int bounce = int((meta >> 10) & 63u);
+    TriRec tr;
+    tr.load(sc, prim);
+    Sampler smp;
+    smp.start(sc, pa.frame_tab + size_t(frame) * 1024u, pix & 0xffffu, pix >> 16, int(meta & 1023u));
+    // level 3: the light record depends on the first Sobol' value only
+    LightRec lr;
+    float u1 = 0.0f;
+    if (sc.n_lights != 0u) {
+        u1 = smp.s1();
+        uint32_t li = uint32_t(int(u1 * float(sc.n_lights)));  // include/pt/light.h:58-60
+        if (li >= sc.n_lights) li = sc.n_lights - 1u;          // the reference would throw here; clamp instead
+        lr.load(sc, li);
+    }
+
+    const V3 ro{a.x, a.y, a.z}, rd{a.w, b.x, b.y};
+    V3 T{b.z, b.w, c.x};
+    const float brdfPdf = c.y;
+    Surf it;
+    complete(tr, h0.z, h0.w, it);
+    const V3 wo = -rd;
+    const Mat m = surface_material(sc, tr, prim, h0.z, h0.w);
+
+    // emitted radiance with MIS against light sampling (src/integrator.cpp:58-69)
+    if (tr.light_id() >= 0) {
+        const V3 Le = dot(it.n, wo) > 0.0f ? tr.lemit() : mk3(0.0f);
+        V3 add;
+        if (bounce == 0) {
+            add = cmul(T, Le);
+        } else {
+            float lpdf = light_pdf(tr.inv_area(), it.p, it.n, ro, rd);
+            lpdf *= 1.0f / float(sc.n_lights);
+            const float w = power_heuristic(brdfPdf, lpdf);
+            add = w * cmul(T, Le);
+        }
+        float4 L = lbuf[slot];
+        L.x += add.x;
+        L.y += add.y;
+        L.z += add.z;
+        lbuf[slot] = L;
+    }
+
+    // light sampling (src/integrator.cpp:109-141)
+    if (sc.n_lights != 0u) {
+        const float selectPdf = 1.0f / float(sc.n_lights);
+        const LiSample ls = light_sample(lr, it.p, it.n, smp.s2());
+        if (ls.pdfDir != 0.0f) {
+            // Scene::unocculded (src/scene.cpp:213-220)
+            const V3 p0 = it.p + it.n * kEps, p1 = ls.p + ls.n * kEps;
+            const V3 d = p1 - p0;
+            const float dist = norm(d);
+            const V3 sd = d / dist;
+            V3 f;
+            float bp;
+            brdf_eval_pdf(m, it.n, wo, ls.wi, f, bp);
+            const float cosTheta = dot(it.n, ls.wi);
+            const float lp = ls.pdfDir * selectPdf;
+            const float w = power_heuristic(lp, bp);
+            const V3 Ld = w * cmul(f, ls.L) * cosTheta / lp;
+            const V3 contrib = cmul(T, Ld);
+            o.want_shadow = true;
+            o.sa = make_float4(p0.x, p0.y, p0.z, sd.x);
+            o.sb = make_float4(sd.y, sd.z, dist * (1 - kEps), as_f(slot));
+            o.sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+        }
+    }
+
+    // BRDF sampling; the 2-D sample is drawn before the 1-D one (src/integrator.cpp:83, right-to-left arguments)
+    const V2 u = smp.s2();
+    const float uc = smp.s1();
+    const BSample bs = brdf_sample(m, it, wo, uc, u);
+    float newPdf = brdfPdf;
+    bool go = true;
+    if (bs.specular) {
+        bounce--;
+        newPdf = 1.0f;
+    } else {
+        if (sqnorm(bs.f) == 0.0f || bs.pdf == 0.0f) go = false;
+        if (go) {
+            const V3 thr = bs.f * dot(it.n, bs.wi) / bs.pdf;
+            T = cmul(T, thr);
+            newPdf = bs.pdf;
+        }
+    }
+    if (go) {
+        const V3 no = it.p + it.ng * kEps;  // Intersection::genRay (src/shape.cpp:186-189)
+        // Russian roulette (src/integrator.cpp:99-103)
+        if (maxc(T) < 1.0f && bounce > 1) {
+            const float qq = std_max(0.0f, 1.0f - maxc(T));
+            if (smp.s1() < qq) go = false;
+            T = T / (1.0f - qq);
+        }
+        bounce++;
+        if (go && bounce < int(pa.max_bounce)) {
+            o.cont = true;
+            o.na = make_float4(no.x, no.y, no.z, bs.wi.x);
+            o.nb = make_float4(bs.wi.y, bs.wi.z, T.x, T.y);
+            // the sampler wraps lazily (dim == 1024 after drawing dimension 1023): store the dimension the next
+            // draw would wrap to (src/sampler.cpp:102-114), so that it fits the 10-bit field
+            const uint32_t next_dim = smp.dim >= 1024 ? 2u : uint32_t(smp.dim);
+            o.nc = make_float4(T.z, newPdf, as_f(pix), as_f(next_dim | (uint32_t(bounce) << 10) | (frame << 16)));
+        }
+    }
+}
+
+// shade_hit for every entry of the hit lists: the shadow ray goes to the shadow queue, the continued path to the next
+// path queue.  165 registers, 3 waves per SIMD; capping the registers for a fourth wave spills and is slower (measured:
+// 58 against 42.5 ms per 128-spp pass of the 1.6 M triangle interior), as is a fifth or sixth.
 __global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq, PathQ in, PathQ out, ShadowQ sh, float4* lbuf, ZeroList zl) {
     const uint32_t shard = shard_index();
     zero_counters(zl, shard);
@@ -640,136 +761,87 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq
     const uint32_t n = hq.count[shard];
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t j = base + threadIdx.x;
-        bool cont = false, want_shadow = false;
-        float4 na{}, nb{}, nc{}, sa{}, sb{}, sc4{};
+        ShadeOut o;
         uint32_t slot = 0;
         if (j < n) {
             const float4 h0 = hq.h0[sbase + j], h1 = hq.h1[sbase + j];
             const size_t pi = sbase + as_u(h0.x);
-            const uint32_t prim = as_u(h0.y);
-            const uint32_t pix = as_u(h1.x), meta = as_u(h1.y);
-            const uint32_t frame = meta >> 16;
-            int bounce = int((meta >> 10) & 63u);
-            // level 2 reads
-            const float4 a = in.a[pi], b = in.b[pi], c = in.c[pi];
+            const float4 a = in.a[pi], b = in.b[pi], c = in.c[pi];  // level 2 reads
             slot = in.slot[pi];
-            TriRec tr;
-            tr.load(sc, prim);
-            Sampler smp;
-            smp.start(sc, pa.frame_tab + size_t(frame) * 1024u, pix & 0xffffu, pix >> 16, int(meta & 1023u));
-            // level 3: the light record depends on the first Sobol' value only
-            LightRec lr;
-            float u1 = 0.0f;
-            if (sc.n_lights != 0u) {
-                u1 = smp.s1();
-                uint32_t li = uint32_t(int(u1 * float(sc.n_lights)));  // include/pt/light.h:58-60
-                if (li >= sc.n_lights) li = sc.n_lights - 1u;          // the reference would throw here; clamp instead
-                lr.load(sc, li);
-            }
-
-            const V3 ro{a.x, a.y, a.z}, rd{a.w, b.x, b.y};
-            V3 T{b.z, b.w, c.x};
-            const float brdfPdf = c.y;
-            Surf it;
-            complete(tr, h0.z, h0.w, it);
-            const V3 wo = -rd;
-            const Mat m = surface_material(sc, tr, prim, h0.z, h0.w);
-
-            // emitted radiance with MIS against light sampling (src/integrator.cpp:58-69)
-            if (tr.light_id() >= 0) {
-                const V3 Le = dot(it.n, wo) > 0.0f ? tr.lemit() : mk3(0.0f);
-                V3 add;
-                if (bounce == 0) {
-                    add = cmul(T, Le);
-                } else {
-                    float lpdf = light_pdf(tr.inv_area(), it.p, it.n, ro, rd);
-                    lpdf *= 1.0f / float(sc.n_lights);
-                    const float w = power_heuristic(brdfPdf, lpdf);
-                    add = w * cmul(T, Le);
-                }
-                float4 L = lbuf[slot];
-                L.x += add.x;
-                L.y += add.y;
-                L.z += add.z;
-                lbuf[slot] = L;
-            }
-
-            // light sampling (src/integrator.cpp:109-141)
-            if (sc.n_lights != 0u) {
-                const float selectPdf = 1.0f / float(sc.n_lights);
-                const LiSample ls = light_sample(lr, it.p, it.n, smp.s2());
-                if (ls.pdfDir != 0.0f) {
-                    // Scene::unocculded (src/scene.cpp:213-220)
-                    const V3 p0 = it.p + it.n * kEps, p1 = ls.p + ls.n * kEps;
-                    const V3 d = p1 - p0;
-                    const float dist = norm(d);
-                    const V3 sd = d / dist;
-                    V3 f;
-                    float bp;
-                    brdf_eval_pdf(m, it.n, wo, ls.wi, f, bp);
-                    const float cosTheta = dot(it.n, ls.wi);
-                    const float lp = ls.pdfDir * selectPdf;
-                    const float w = power_heuristic(lp, bp);
-                    const V3 Ld = w * cmul(f, ls.L) * cosTheta / lp;
-                    const V3 contrib = cmul(T, Ld);
-                    want_shadow = true;
-                    sa = make_float4(p0.x, p0.y, p0.z, sd.x);
-                    sb = make_float4(sd.y, sd.z, dist * (1 - kEps), as_f(slot));
-                    sc4 = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
-                }
-            }
-
-            // BRDF sampling; the 2-D sample is drawn before the 1-D one (src/integrator.cpp:83, right-to-left arguments)
-            const V2 u = smp.s2();
-            const float uc = smp.s1();
-            const BSample bs = brdf_sample(m, it, wo, uc, u);
-            float newPdf = brdfPdf;
-            bool go = true;
-            if (bs.specular) {
-                bounce--;
-                newPdf = 1.0f;
-            } else {
-                if (sqnorm(bs.f) == 0.0f || bs.pdf == 0.0f) go = false;
-                if (go) {
-                    const V3 thr = bs.f * dot(it.n, bs.wi) / bs.pdf;
-                    T = cmul(T, thr);
-                    newPdf = bs.pdf;
-                }
-            }
-            if (go) {
-                const V3 no = it.p + it.ng * kEps;  // Intersection::genRay (src/shape.cpp:186-189)
-                // Russian roulette (src/integrator.cpp:99-103)
-                if (maxc(T) < 1.0f && bounce > 1) {
-                    const float qq = std_max(0.0f, 1.0f - maxc(T));
-                    if (smp.s1() < qq) go = false;
-                    T = T / (1.0f - qq);
-                }
-                bounce++;
-                if (go && bounce < int(pa.max_bounce)) {
-                    cont = true;
-                    na = make_float4(no.x, no.y, no.z, bs.wi.x);
-                    nb = make_float4(bs.wi.y, bs.wi.z, T.x, T.y);
-                    // the sampler wraps lazily (dim == 1024 after drawing dimension 1023): store the dimension the next
-                    // draw would wrap to (src/sampler.cpp:102-114), so that it fits the 10-bit field
-                    const uint32_t next_dim = smp.dim >= 1024 ? 2u : uint32_t(smp.dim);
-                    nc = make_float4(T.z, newPdf, as_f(pix), as_f(next_dim | (uint32_t(bounce) << 10) | (frame << 16)));
-                }
-            }
+            shade_hit(sc, pa, h0, h1, a, b, c, slot, lbuf, o);
         }
-        const uint32_t sl = wave_alloc(want_shadow, sh.count + shard);
-        if (want_shadow) {
-            sh.a[sbase + sl] = sa;
-            sh.b[sbase + sl] = sb;
-            sh.c[sbase + sl] = sc4;
+        const uint32_t sl = wave_alloc(o.want_shadow, sh.count + shard);
+        if (o.want_shadow) {
+            sh.a[sbase + sl] = o.sa;
+            sh.b[sbase + sl] = o.sb;
+            sh.c[sbase + sl] = o.sc4;
         }
-        const uint32_t nl = wave_alloc(cont, out.count + shard);
-        if (cont) {
-            out.a[sbase + nl] = na;
-            out.b[sbase + nl] = nb;
-            out.c[sbase + nl] = nc;
+        const uint32_t nl = wave_alloc(o.cont, out.count + shard);
+        if (o.cont) {
+            out.a[sbase + nl] = o.na;
+            out.b[sbase + nl] = o.nb;
+            out.c[sbase + nl] = o.nc;
             out.slot[sbase + nl] = slot;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ finish
+
+// The remaining iterations of a few paths in one launch.  A specular bounce is not counted (src/integrator.cpp:84-87), so
+// once every path has had maxBounce iterations only chains of mirror reflections are left -- often a handful of paths
+// that go on for thousands of iterations (a mirror with interpolated normals reflects rays below its own surface, and
+// such a path creeps along a crease).  Three launches and a counter read-back per iteration would be all overhead then.
+// Here one wave takes one path -- entry `j` of the hit list of shard `shard`, both from `entries` -- and its first lane
+// runs shade, visibility test and next intersection, all in the reference's visit order, until the path ends: a chain of
+// dependent memory accesses either way, and a wave to itself keeps it free of divergence (paths in the lanes of one wave
+// are in different phases all the time; measured 18 us per iteration against 4).  misc[16..19] receive the numbers of
+// closest-hit and any-hit queries as two 64-bit totals.
+constexpr int kFinishBlock = 64;
+template <class C>
+__global__ __launch_bounds__(kFinishBlock) void k_finish(DevScene sc, PassArgs pa, HitQ hq, PathQ q, const uint2* entries, float4* lbuf,
+                                                         uint32_t max_iterations, uint32_t* misc) {
+    __shared__ uint32_t s_stack[kLdsDepth * kBlock];  // the stack's rows are kBlock words apart
+    const uint2 e = entries[blockIdx.x];
+    const size_t sbase = size_t(e.x) * kShard;
+    C wce, wcs;
+    uint32_t n_closest = 0, n_any = 0;
+    if (threadIdx.x == 0 && e.y < hq.count[e.x]) {
+        float4 h0 = hq.h0[sbase + e.y], h1 = hq.h1[sbase + e.y];
+        const size_t pi = sbase + as_u(h0.x);
+        float4 a = q.a[pi], b = q.b[pi], c = q.c[pi];
+        const uint32_t slot = q.slot[pi];
+        for (uint32_t it = 0; it < max_iterations; ++it) {
+            ShadeOut o;
+            shade_hit(sc, pa, h0, h1, a, b, c, slot, lbuf, o);
+            if (o.want_shadow) {
+                const RayD sr{V3{o.sa.x, o.sa.y, o.sa.z}, V3{o.sa.w, o.sb.x, o.sb.y}, 0.0f, o.sb.z};
+                int32_t first_prim;
+                ++n_any;
+                if (!any_exact(sc, sr, first_prim, s_stack, wcs)) {
+                    float4 L = lbuf[slot];
+                    L.x += o.sc4.x;
+                    L.y += o.sc4.y;
+                    L.z += o.sc4.z;
+                    lbuf[slot] = L;
+                }
+            }
+            if (!o.cont) break;
+            const RayD ray{V3{o.na.x, o.na.y, o.na.z}, V3{o.na.w, o.nb.x, o.nb.y}, 0.0f, __builtin_huge_valf()};
+            HitD h;
+            ++n_closest;
+            if (!closest_exact(sc, ray, h, s_stack, wce)) break;
+            a = o.na;
+            b = o.nb;
+            c = o.nc;
+            h0 = make_float4(0.0f, as_f(uint32_t(h.prim)), h.u, h.v);
+            h1 = make_float4(c.z, c.w, h.t, 0.0f);
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(misc + 16), (unsigned long long)n_closest);
+        atomicAdd(reinterpret_cast<unsigned long long*>(misc + 18), (unsigned long long)n_any);
+    }
+    flush_counts(wce, misc, 1);
+    flush_counts(wcs, misc, 2);
 }
 
 // ------------------------------------------------------------------------------------------------ film
@@ -912,6 +984,17 @@ __global__ void k_probe_box(DevScene sc, const float* boxes6, const float4* rays
 
 // Triangle::intersect (src/shape.cpp:50-89) for explicit (triangle, ray) pairs on the record form the leaf array holds
 // ({p0, p1 - p0, p2 - p0}); tuv receives t, u, v of accepted hits (zeros otherwise).
+// sin, cos of x[i] and x[i] ^ y[i] as the shading code computes them
+__global__ void k_probe_math(const float* x, const float* y, uint32_t n, float* out3) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float sn, cs;
+    sincos_f(x[i], sn, cs);
+    out3[3 * size_t(i)] = sn;
+    out3[3 * size_t(i) + 1] = cs;
+    out3[3 * size_t(i) + 2] = pow_r(x[i], y[i]);
+}
+
 __global__ void k_probe_triangle(const float* tri9, const float4* rays, uint32_t n, uint8_t* hit, float* tuv) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -116,6 +116,12 @@ constexpr uint64_t kAutoSlots = uint64_t(2) * 65535 * 4096;  // default number o
 constexpr uint64_t kBytesPerSlot = 224;             // two path queues, hit list, shadow queue, deferred lists, radiance slot
 constexpr int kRing = 4;  // counter snapshots in flight between the stream and the host
 
+// Once every path has had max_bounce iterations (only chains of specular bounces are left) and at most this many paths
+// are alive, one launch of k_finish runs them to their end, a wave per path: as many as the chip holds at once (256 CUs
+// x 8 waves at that kernel's register count).  More paths than that are better off in the regular loop, whose cost per
+// iteration does not depend on their number.
+constexpr uint32_t kFinishPaths = 2048;
+
 struct Workspace {
     uint32_t cap_slots = 0;   // padded to whole shards
     uint32_t n_shards = 0;
@@ -138,6 +144,7 @@ struct Workspace {
     hipEvent_t ring_ev[kRing] = {};
     uint32_t* frame_tab = nullptr;
     size_t frame_cap = 0;  // in frames
+    uint2* finish_list = nullptr;  // (shard, hit-list entry) pairs handed to k_finish (kFinishPaths of them)
     std::vector<void*> owned;
     size_t misc_offset() const { return (size_t(11) * n_shards + 1) & ~size_t(1); }  // 64-bit atomics live in misc: keep it 8-byte aligned
     size_t counter_words() const { return misc_offset() + kMiscWords; }
@@ -699,6 +706,7 @@ int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
         if (int rc = ws_alloc(ws, &ws.lbuf, padded)) return rc;
         if (int rc = ws_alloc(ws, &ws.counters, ws.counter_words())) return rc;
         if (int rc = ws_alloc(ws, &ws.frame_tab, n_frames * 1024)) return rc;
+        if (int rc = ws_alloc(ws, &ws.finish_list, kFinishPaths)) return rc;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ws.h_counters), (size_t(kRing) * ws.snapshot_words() + kMiscWords) * sizeof(uint32_t),
                               hipHostMallocDefault));
         for (hipEvent_t& e : ws.ring_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -844,6 +852,8 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
     const bool fast = pa.traversal == PT_TRAVERSE_FAST;
     uint32_t bound = std::min<uint32_t>(kShard, pa.n_slots);  // upper bound of every shard fill from here on
     bool finished = false;
+    uint64_t live = ~0ull;                 // paths alive after the latest snapshot read
+    const uint32_t* live_counts = nullptr;  // ... per shard (in the pinned ring: valid until kRing more snapshots are queued)
     uint32_t launched = 0, consumed = 0;  // snapshots queued / read; snapshot i describes bounce i (taken after its shade)
     auto consume = [&](bool wait) -> int {
         while (consumed < launched) {
@@ -864,6 +874,8 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
             }
             bound = std::min(bound, std::max(next.max, 1u));
             if (next.max == 0) finished = true;
+            live = next.sum;
+            live_counts = c + size_t(nxt) * K;
             ++consumed;
         }
         return PT_OK;
@@ -876,6 +888,33 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
     for (uint32_t iter = 0; iter < kMaxIterations; ++iter) {
         if (int rc = consume(true)) return rc;  // the previous bounce's snapshot
         if (finished) break;
+        if (iter >= pa.max_bounce && live <= kFinishPaths) {
+            // `launched == consumed` here: live_counts describes the queue that the hit list of this iteration came from
+            // (a shard's hit list is at most as long as the path queue it came from)
+            std::vector<uint2> list;
+            for (uint32_t k = 0; k < K; ++k)
+                for (uint32_t j = 0; j < live_counts[k]; ++j) list.push_back(make_uint2(k, j));
+            const int cur = int(iter & 1u);
+            ws.hq.count = ws.hit_count[cur];
+            HIP_TRY(hipMemcpyAsync(ws.finish_list, list.data(), list.size() * sizeof(uint2), hipMemcpyHostToDevice, g_stream));
+            if (int rc = tm.begin(PT_K_FINISH)) return rc;
+            const uint32_t left = kMaxIterations - iter;
+            if (count)
+                hipLaunchKernelGGL(k_finish<Count>, dim3(uint32_t(list.size())), dim3(kFinishBlock), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.finish_list, ws.lbuf,
+                                   left, ws.misc);
+            else
+                hipLaunchKernelGGL(k_finish<NoCount>, dim3(uint32_t(list.size())), dim3(kFinishBlock), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.finish_list,
+                                   ws.lbuf, left, ws.misc);
+            if (int rc = tm.end()) return rc;
+            uint32_t* h = ws.h_misc() + 16;
+            HIP_TRY(hipMemcpyAsync(h, ws.misc + 16, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+            HIP_TRY(hipStreamSynchronize(g_stream));  // `list` must outlive its copy, and the totals are read now
+            if (st) {
+                st->closest_rays += uint64_t(h[0]) | (uint64_t(h[1]) << 32);
+                st->any_rays += uint64_t(h[2]) | (uint64_t(h[3]) << 32);
+            }
+            break;
+        }
         if (iter != 0 && iter % 256u == 0) {  // long chains: fold the timing events in now instead of keeping three pairs per iteration
             HIP_TRY(hipStreamSynchronize(g_stream));
             if (int rc = tm.collect(st)) return rc;
@@ -1661,6 +1700,22 @@ int pt_hip_probe_triangle(const float* tri9, const pt_ray* rays, size_t n, uint8
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hit, d_hit, n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(tuv, d_tuv, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_hip_probe_math(const float* x, const float* y, size_t n, float* sin_cos_pow) {
+    if (int rc = bind_default()) return rc;
+    if (n == 0) return PT_OK;
+    if (!x || !y || !sin_cos_pow || n > 0x7fffffffull) return fail(PT_ERR_INVALID, "bad argument");
+    ProbeBuffers pb;
+    float *d_x = nullptr, *d_y = nullptr, *d_out = nullptr;
+    if (int rc = pb.in(x, n, &d_x)) return rc;
+    if (int rc = pb.in(y, n, &d_y)) return rc;
+    if (int rc = pb.in<float>(nullptr, 3 * n, &d_out)) return rc;
+    hipLaunchKernelGGL(k_probe_math, dim3(blocks(uint32_t(n), 256)), dim3(256), 0, g_stream, d_x, d_y, uint32_t(n), d_out);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(sin_cos_pow, d_out, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

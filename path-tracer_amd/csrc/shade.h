@@ -125,16 +125,130 @@ PTD bool is_mirror(const Mat& m) { return m.ks.x > 999.0f || m.ks.y > 999.0f || 
 // mix() on floats (include/pt/common.h:82-85): a * (1.0 - f) is a double product, b * f a float product
 PTD float mixf(float a, float b, float f) { return float(double(a) * (1.0 - double(f)) + double(b * f)); }
 PTD V3 reflect(V3 w, V3 n) { return -w + (2.0f * dot(w, n)) * n; }  // include/pt/common.h:87-89
-PTD V3 cosine_hemisphere(V2 u) {                                     // include/pt/common.h:100-104
-    const float su0 = sqrtf(u.x);
-    const float phi = 2.0f * kPi * u.y;
-    return V3{su0 * cosf(phi), su0 * sinf(phi), sqrtf(1.0f - u.x)};
+// cosf, sinf and powf of the host's C library (which the reference calls) are correctly rounded in 98.7 - 99.9 % of their
+// results (measured against glibc 2.35); the device library's single-precision versions agree with them in 79 - 91 %.
+// Evaluating in double and rounding once gives the correctly rounded float in all but a few results per million, so that
+// nearly every bounce direction and BRDF value carries the bits the reference computes (a last-bit difference flips
+// Russian-roulette and lobe decisions now and then, after which a path has nothing in common with the reference's).
+// The double-precision kernels below are sized for that job only (relative error below 1e-13, arguments as the shading
+// code produces them) and cost a third of the device library's general ones.
+#ifndef PT_LIBM_F64
+#define PT_LIBM_F64 2  // 0: device library in single precision, 1: device library in double, 2: the kernels below
+#endif
+
+// cos and sin of a float angle in [0, 8]: quadrant by Cody-Waite with pi/2 in two pieces, Taylor polynomials to r^15 / r^14
+// on |r| <= pi/4 (remainders below 5e-17 and 1.1e-15).  Anything else goes to the device library.
+PTD void sincos_r(float xf, float& sn, float& cs) {
+    if (!(xf >= 0.0f && xf <= 8.0f)) {
+        sn = float(sin(double(xf)));
+        cs = float(cos(double(xf)));
+        return;
+    }
+    const double x = double(xf);
+    const double k = __builtin_rint(x * 0.63661977236758134308);  // 2 / pi
+    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = -7.6471637318198164759e-13;                       // -1/15!
+    ps = __builtin_fma(ps, z, 1.6059043836821614599e-10);          //  1/13!
+    ps = __builtin_fma(ps, z, -2.5052108385441718775e-08);         // -1/11!
+    ps = __builtin_fma(ps, z, 2.7557319223985890653e-06);          //  1/9!
+    ps = __builtin_fma(ps, z, -1.9841269841269841270e-04);         // -1/7!
+    ps = __builtin_fma(ps, z, 8.3333333333333333333e-03);          //  1/5!
+    ps = __builtin_fma(ps, z, -1.6666666666666666667e-01);         // -1/3!
+    const double s = __builtin_fma(r * z, ps, r);
+    double pc = -1.1470745597729724714e-11;                       // -1/14!
+    pc = __builtin_fma(pc, z, 2.0876756987868098979e-09);          //  1/12!
+    pc = __builtin_fma(pc, z, -2.7557319223985890653e-07);         // -1/10!
+    pc = __builtin_fma(pc, z, 2.4801587301587301587e-05);          //  1/8!
+    pc = __builtin_fma(pc, z, -1.3888888888888888889e-03);         // -1/6!
+    pc = __builtin_fma(pc, z, 4.1666666666666666667e-02);          //  1/4!
+    pc = __builtin_fma(pc, z, -0.5);
+    const double c = __builtin_fma(pc, z, 1.0);
+    const int q = int(k) & 3;
+    const double so = (q & 1) ? c : s, co = (q & 1) ? s : c;
+    sn = float((q & 2) ? -so : so);
+    cs = float(((q + 1) & 2) ? -co : co);
 }
-PTD V3 phong_lobe(V2 u, float sh) {  // include/pt/common.h:107-112
-    const float ct = powf(u.x, 1.0f / (sh + 1.0f));
+
+// x^y for finite x > 0 and finite y as 2^(y log2 x): log through 2 atanh((m - 1) / (m + 1)) with the mantissa m in
+// [sqrt(1/2), sqrt(2)) (series to s^20, remainder below 3e-17), 2^f on |f| <= 1/2 by the Taylor series of e^(f ln 2)
+// to degree 13 (remainder below 4e-18); the one rounding to float also produces the denormal results.  Results near
+// overflow, negative bases, -0 and non-finite operands go to the device library.
+// (a real call, not inlined: three inlined copies cost k_shade 56 registers and with them a third of its waves)
+__device__ __attribute__((noinline)) float pow_k(float xf, float yf) {
+    const double x = double(xf), y = double(yf);
+    if (as_u(xf) == 0u && yf > 0.0f) return 0.0f;  // +0 to a positive power
+    if (!(xf > 0.0f && xf < __builtin_huge_valf() && __builtin_fabsf(yf) < __builtin_huge_valf())) return float(pow(x, y));
+    int e;
+    double m = __builtin_frexp(x, &e);
+    if (m < 0.70710678118654752440) {
+        m *= 2.0;
+        e -= 1;
+    }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = __builtin_fma(p, z, 1.0 / 19.0);
+    p = __builtin_fma(p, z, 1.0 / 17.0);
+    p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, 1.0 / 11.0);
+    p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0);
+    p = __builtin_fma(p, z, 1.0 / 3.0);
+    const double ln_m = 2.0 * __builtin_fma(s * z, p, s);
+    const double l2 = __builtin_fma(ln_m, 1.44269504088896340736, double(e));  // log2 x
+    const double w = y * l2;
+    if (w < -150.5) return 0.0f;  // below half of the smallest denormal
+    if (!(w < 127.0)) return float(pow(x, y));
+    const double n = __builtin_rint(w);
+    const double t = (w - n) * 0.69314718055994530942;
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, t, 1.0 / 479001600.0);
+    q = __builtin_fma(q, t, 1.0 / 39916800.0);
+    q = __builtin_fma(q, t, 1.0 / 3628800.0);
+    q = __builtin_fma(q, t, 1.0 / 362880.0);
+    q = __builtin_fma(q, t, 1.0 / 40320.0);
+    q = __builtin_fma(q, t, 1.0 / 5040.0);
+    q = __builtin_fma(q, t, 1.0 / 720.0);
+    q = __builtin_fma(q, t, 1.0 / 120.0);
+    q = __builtin_fma(q, t, 1.0 / 24.0);
+    q = __builtin_fma(q, t, 1.0 / 6.0);
+    q = __builtin_fma(q, t, 0.5);
+    q = __builtin_fma(q, t, 1.0);
+    q = __builtin_fma(q, t, 1.0);
+    return float(__builtin_ldexp(q, int(n)));
+}
+
+#if PT_LIBM_F64 == 2
+PTD void sincos_f(float x, float& s, float& c) { sincos_r(x, s, c); }
+PTD float pow_r(float x, float y) { return pow_k(x, y); }
+#elif PT_LIBM_F64 == 1
+PTD void sincos_f(float x, float& s, float& c) {
+    s = float(sin(double(x)));
+    c = float(cos(double(x)));
+}
+PTD float pow_r(float x, float y) { return float(pow(double(x), double(y))); }
+#else
+PTD void sincos_f(float x, float& s, float& c) {
+    s = sinf(x);
+    c = cosf(x);
+}
+PTD float pow_r(float x, float y) { return powf(x, y); }
+#endif
+// squareToCosineHemisphere and the Phong lobe (include/pt/common.h:100-112) share their azimuth phi = 2 pi u.y: its sine
+// and cosine are passed in, so that the two branches of sampleBRDF need them only once
+PTD float azimuth(V2 u) { return 2.0f * kPi * u.y; }
+PTD V3 cosine_hemisphere(V2 u, float sn, float cs) {  // include/pt/common.h:100-104
+    const float su0 = sqrtf(u.x);
+    return V3{su0 * cs, su0 * sn, sqrtf(1.0f - u.x)};
+}
+PTD V3 phong_lobe(V2 u, float sh, float sn, float cs) {  // include/pt/common.h:107-112
+    const float ct = pow_r(u.x, 1.0f / (sh + 1.0f));
     const float st = sqrtf(1.0f - ct * ct);
-    const float phi = 2.0f * kPi * u.y;
-    return V3{st * cosf(phi), st * sinf(phi), ct};
+    return V3{st * cs, st * sn, ct};
 }
 
 // Material::BRDF (src/material.cpp:18-38) and Material::pdf (src/material.cpp:92-115) for the same pair of directions
@@ -147,7 +261,7 @@ PTD void brdf_eval_pdf(const Mat& m, V3 n, V3 wo, V3 wi, V3& f, float& pdf) {
     }
     const V3 r = reflect(wo, n);
     const float cosRV = std_max(dot(wi, r), 0.0f);
-    const float powRV = powf(cosRV, m.ns);
+    const float powRV = pow_r(cosRV, m.ns);
     const float normalization = (m.ns + 2.0f) * kInvTwoPi;
     f = m.kd * kInvPi + m.ks * normalization * powRV;
     const float sumKd = sum3(m.kd), sumKs = sum3(m.ks);
@@ -182,18 +296,20 @@ PTD BSample brdf_sample(const Mat& m, const Surf& it, V3 wo, float uc, V2 u) {
     if (sumKdKs == 0.0f) return out;
     const float specProb = sumKs / sumKdKs;
     const V3 r = reflect(wo, it.n);
+    float sn, cs;
+    sincos_f(azimuth(u), sn, cs);
     V3 wi;
     if (uc < specProb) {
         const Frame ts(r);
-        wi = ts.to_world(phong_lobe(u, m.ns));
+        wi = ts.to_world(phong_lobe(u, m.ns, sn, cs));
     } else {
-        wi = it.ts.to_world(cosine_hemisphere(u));
+        wi = it.ts.to_world(cosine_hemisphere(u, sn, cs));
     }
     wi = normalized(wi);
     const float cosTheta = dot(wi, it.n);
     if (cosTheta < 0.0f) return out;
     const float cosRV = std_max(dot(wi, r), 0.0f);
-    const float powRV = powf(cosRV, m.ns);
+    const float powRV = pow_r(cosRV, m.ns);
     const float pdf_spec = (m.ns + 1.0f) * kInvTwoPi * powRV;
     const float pdf_diff = cosTheta * kInvPi;
     out.f = m.kd * kInvPi + m.ks * (m.ns + 2.0f) * kInvTwoPi * powRV;

@@ -14,7 +14,7 @@ TRAVERSE_EXACT, TRAVERSE_FAST = 0, 1
 FLAG_NO_KERNEL_TIMING, FLAG_COUNT_WORK = 1, 2
 INTEGRATOR_PATH, INTEGRATOR_NORMAL, INTEGRATOR_ALBEDO = 0, 1, 2
 NOALLOC_MAX_RAYS = 67108864      # PT_NOALLOC_MAX_RAYS
-KERNEL_NAMES = ["generate", "extend", "shade", "shadow", "film", "retrace", "k6", "k7"]
+KERNEL_NAMES = ["generate", "extend", "shade", "shadow", "film", "retrace", "finish", "k7"]
 
 c_f32p = C.POINTER(C.c_float)
 c_u32p = C.POINTER(C.c_uint32)
@@ -124,6 +124,7 @@ def hip_lib():
         L.pt_hip_selftest_division.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         L.pt_hip_probe_box.argtypes = [c_f32p, C.c_void_p, C.c_size_t, c_u8p]
         L.pt_hip_probe_triangle.argtypes = [c_f32p, C.c_void_p, C.c_size_t, c_u8p, c_f32p]
+        L.pt_hip_probe_math.argtypes = [c_f32p, c_f32p, C.c_size_t, c_f32p]
         L.pt_hip_build_bvh.argtypes = [c_f32p, C.c_uint32, c_u32p, C.c_uint32, C.POINTER(C.POINTER(BvhNode)), c_u32p, C.POINTER(c_u32p), c_u32p]
         L.pt_hip_free.argtypes = [C.c_void_p]
         _hip = L
@@ -396,6 +397,15 @@ def probe_triangle(tri9, rays, device=0):
     hit, tuv = np.zeros(len(rays), np.uint8), np.zeros((len(rays), 3), np.float32)
     _chk(hip_lib().pt_hip_probe_triangle(_p(tri9, c_f32p), rays.ctypes.data_as(C.c_void_p), len(rays), _p(hit, c_u8p), _p(tuv, c_f32p)))
     return hit, tuv
+
+
+def probe_math(x, y, device=0):
+    """The shading code's sin(x), cos(x) and x ** y for explicit float32 operands -> float32[n, 3]."""
+    init(device)
+    x, y = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32)
+    out = np.zeros((len(x), 3), np.float32)
+    _chk(hip_lib().pt_hip_probe_math(_p(x, c_f32p), _p(y, c_f32p), len(x), _p(out, c_f32p)))
+    return out
 
 
 def film_to_image(film):

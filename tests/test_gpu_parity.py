@@ -482,6 +482,47 @@ def test_textured_materials_and_vertex_normals_match_oracle():
     g.close()
 
 
+def test_shading_sine_cosine_and_power_are_correctly_rounded():
+    """The reference calls the C library's sinf / cosf (include/pt/common.h:103, 111) and powf (include/pt/common.h:108,
+    src/material.cpp:34, 79, 108).  The kernels evaluate them in double and round once: the correctly rounded float, which
+    is what glibc returns in all but 1.3 % (sine, cosine) and 0.1 % (power) of the cases; the single-precision device
+    library would agree with glibc in 79 - 91 % only.  Checked against float64 results rounded to float32 and against the
+    C library of this machine."""
+    libm = C.CDLL("libm.so.6")
+    for name in ("sinf", "cosf"):
+        getattr(libm, name).restype, getattr(libm, name).argtypes = C.c_float, [C.c_float]
+    libm.powf.restype, libm.powf.argtypes = C.c_float, [C.c_float, C.c_float]
+    rng = np.random.default_rng(1)
+    n = 100000
+    u = rng.random(n, dtype=np.float32)
+    phi = (np.float32(2 * np.pi) * u).astype(np.float32)          # the only angles the shading code forms
+    phi[:8] = [0, np.pi, np.pi / 2, 2 * np.pi, 1.5 * np.pi, 1e-30, 7.9, 6.2831855]
+    ns = rng.choice(np.array([0, 1, 2, 4, 6, 30, 100, 1397.325, 2000, 10000], np.float32), n)
+    x = np.where(rng.random(n) < 0.5, u, np.cos(u * np.float32(1.5))).astype(np.float32)
+    y = np.where(rng.random(n) < 0.5, ns, np.float32(1) / (ns + np.float32(1))).astype(np.float32)
+    special = [(0, 3), (0, 0), (1, 1000), (0.5, 149), (0.5, 140), (0.5, 151), (1.0000001, 1e6), (1e-38, 1), (1e-45, 1), (0.999, 1e5),
+               (2, 127.5), (2, 200), (-0.0, 3), (-0.0, 2.5), (-2, 2), (-2, 0.5), (np.inf, 2), (np.nan, 1), (0.3, np.nan), (0.3, -2), (0, -1)]
+    x[:len(special)], y[:len(special)] = np.array(special, np.float32).T
+    got = api.probe_math(np.concatenate([phi, x]), np.concatenate([np.zeros(n, np.float32), y]))
+    sn, cs, pw = got[:n, 0], got[:n, 1], got[n:, 2]
+    with np.errstate(all="ignore"):
+        want = (np.sin(phi.astype(np.float64)).astype(np.float32), np.cos(phi.astype(np.float64)).astype(np.float32),
+                np.power(x.astype(np.float64), y.astype(np.float64)).astype(np.float32))
+    libc = (np.array([libm.sinf(float(v)) for v in phi], np.float32), np.array([libm.cosf(float(v)) for v in phi], np.float32),
+            np.array([libm.powf(float(a), float(b)) for a, b in zip(x, y)], np.float32))
+
+    def same(a, b):
+        return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b)))
+
+    for dev, cr, lc, floor in ((sn, want[0], libc[0], 0.98), (cs, want[1], libc[1], 0.98), (pw, want[2], libc[2], 0.998)):
+        assert same(dev, cr).mean() > 0.9999            # float64 results are themselves off by up to half an ulp of double
+        fin = np.isfinite(cr) & np.isfinite(dev)
+        assert (np.abs(dev[fin].astype(np.float64) - cr[fin]) <= np.spacing(np.abs(cr[fin]))).all()   # never more than one ulp
+        assert same(dev, lc).mean() > floor
+    k = len(special)
+    assert same(pw[:k], libc[2][:k]).all()              # zeros, ones, denormal results, overflow, negative bases, NaN
+
+
 def test_mirror_chains_of_thousands_of_reflections_are_followed_to_the_end():
     """A specular bounce does not count towards maxBounce (src/integrator.cpp:84-87).  A mirror with interpolated normals
     reflects some rays below its own surface; such a path creeps along a crease of the pyramid for thousands of
@@ -501,7 +542,7 @@ def test_mirror_chains_of_thousands_of_reflections_are_followed_to_the_end():
     assert (n_rays > 2000).mean() > 0.03                                      # far beyond 8 * maxBounce iterations
     for mode in (api.TRAVERSE_FAST, api.TRAVERSE_EXACT):
         got, _, st = g.li(xy, smp, traversal=mode)
-        assert st["kernel_launches"]["shade"] > 1000
+        assert st["kernel_launches"]["finish"] == 1 and st["closest_rays"] > 0.4 * n_rays.sum()   # shadow rays are the other half
         err = np.abs(got - want).max(1) / (np.abs(want).max(1) + 1e-3)
         # 5 % of these samples are long chains.  A few of them end differently: the first diffuse bounce before the chain
         # differs in the last bit (device cos / sin against glibc's), the creep follows the same crease all the same, and
