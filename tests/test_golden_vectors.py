@@ -69,7 +69,7 @@ def test_gpu_matches_the_committed_vectors(want, veach_gpu, veach_sd):
     rgb, ps, _ = veach_gpu.li(pix, smp, traversal=api.TRAVERSE_FAST)
     assert np.array_equal(ps.view(np.uint32), want["li_pixel_sample"].view(np.uint32))
     err = np.abs(rgb - want["li_rgb"]).max(1) / (np.abs(want["li_rgb"]).max(1) + 1e-3)
-    assert (err < 1e-3).mean() >= 0.99                                     # device sin / cos / pow differ from libm's by ulps
+    assert (err < 1e-3).mean() >= 0.998 and (err == 0).mean() >= 0.98   # identical in every bit: measured 99.3 - 100 %
 
 
 @pytest.mark.gpu

@@ -1,7 +1,9 @@
 """GPU parity: the HIP path, called through the C ABI (libpt_hip.so), against the CPU oracle on the same inputs.
 
-Bars: bit-exact for hit triangle index, t, u, v, occlusion flags, first occluder and Sobol' values; radiance within the
-stated tolerances (device sin/cos/pow differ from glibc's by ulps, so paths can diverge after the first BRDF sample).
+Bars: bit-exact for hit triangle index, t, u, v, occlusion flags, first occluder and Sobol' values; radiance samples
+identical in every bit for >= 98 % (measured 99.3 - 100 %) and within 1e-3 for >= 99.8 %: the device's sine, cosine and
+power are correctly rounded, glibc's are in all but ~1 % of their results, and a path that meets such a result can
+diverge from there on.
 """
 import ctypes as C
 import os
@@ -340,7 +342,7 @@ def test_per_sample_radiance_matches_oracle(veach_gpu, veach_oracle, veach_sd):
         got, ps, st = veach_gpu.li(pix, smp, traversal=mode)
         assert np.array_equal(ps[:500].view(np.uint32), want_ps.view(np.uint32))     # film positions are bit-exact
         err = np.abs(got - want).max(1) / (np.abs(want).max(1) + 1e-3)
-        assert (err < 1e-3).mean() >= 0.99
+        assert (err < 1e-3).mean() >= 0.998 and (err == 0).mean() >= 0.98   # identical in every bit: measured 99.3 - 100 %
         assert (err == 0).mean() >= 0.5
         assert abs(got.mean() - want.mean()) <= 0.02 * want.mean()
         assert np.isfinite(got).all() and (got >= 0).all()
@@ -478,7 +480,7 @@ def test_textured_materials_and_vertex_normals_match_oracle():
     got = g.li(xy, smp)[0]
     want = np.array([o.li(int(x), int(y), int(s))["rgb"] for (x, y), s in zip(xy, smp)], np.float32)
     err = np.abs(got - want).max(1) / (np.abs(want).max(1) + 1e-3)
-    assert (err < 1e-3).mean() >= 0.99
+    assert (err < 1e-3).mean() >= 0.998 and (err == 0).mean() >= 0.98   # identical in every bit: measured 99.3 - 100 %
     g.close()
 
 
@@ -547,7 +549,7 @@ def test_mirror_chains_of_thousands_of_reflections_are_followed_to_the_end():
         # 5 % of these samples are long chains.  A few of them end differently: the first diffuse bounce before the chain
         # differs in the last bit (device cos / sin against glibc's), the creep follows the same crease all the same, and
         # leaves it at another angle
-        assert (err < 1e-3).mean() >= 0.99
+        assert (err < 1e-3).mean() >= 0.998 and (err == 0).mean() >= 0.98   # identical in every bit: measured 99.3 - 100 %
         assert abs(got.mean() - want.mean()) < 5e-3 * want.mean()
     g.close()
 
@@ -571,7 +573,7 @@ def test_ultra_hd_frame_uses_the_4096_wide_sobol_grid():
     assert (np.floor(ps) == pix).all()
     want_li = np.array([o.li(int(p[0]), int(p[1]), int(s))["rgb"] for p, s in zip(pix, smp)], np.float32)
     err = np.abs(got - want_li).max(1) / (np.abs(want_li).max(1) + 1e-3)
-    assert (err < 1e-3).mean() >= 0.99
+    assert (err < 1e-3).mean() >= 0.998 and (err == 0).mean() >= 0.98   # identical in every bit: measured 99.3 - 100 %
     film, st = g.render(4000, 4001, integrator=api.INTEGRATOR_NORMAL, traversal=api.TRAVERSE_FAST)
     want_film, ost = o.render(4000, 4001, orc.INTEGRATOR_NORMAL)
     assert film.shape == (2164, 3844, 4) and st["closest_rays"] == ost["closest_rays"] == 3840 * 2160
@@ -779,7 +781,7 @@ def test_fifty_million_triangle_ultra_hd_workload_properties():
     want = np.array([o.li(int(p[0]), int(p[1]), int(s))["rgb"] for p, s in zip(pix, smp)], np.float32)
     got = g.li(pix, smp, traversal=api.TRAVERSE_FAST)[0]
     err = np.abs(got - want).max(1) / (np.abs(want).max(1) + 1e-3)
-    assert (err < 1e-3).mean() >= 0.99
+    assert (err < 1e-3).mean() >= 0.998 and (err == 0).mean() >= 0.98   # identical in every bit: measured 99.3 - 100 %
 
     a, sa = g.render(0, 1, traversal=api.TRAVERSE_FAST)
     b, sb = g.render(1, 2, traversal=api.TRAVERSE_FAST)
