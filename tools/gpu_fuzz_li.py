@@ -1,6 +1,6 @@
 """Scratch: per-sample radiance of the HIP path tracer against the CPU oracle on random scenes (materials, lights, textures,
 camera and frame size drawn at random on top of the scene generators).  The tolerance is the test suite's: film positions
-bit for bit, >= 99 % of the samples within 1e-3 relative, means within 2 %.  Usage: gpu_fuzz_li.py <scenes> <samples>"""
+bit for bit, >= 99.5 % of the samples within 1e-3 relative, >= 95 % identical in every bit, means within 2 %.  Usage: gpu_fuzz_li.py <scenes> <samples>"""
 import sys
 sys.path[:0] = ['path-tracer_amd/python', '.', 'oracle']
 import numpy as np
@@ -42,7 +42,7 @@ for seed in (only or range(seeds)):
     ok_ps = np.array_equal(ps.view(np.uint32), want_ps.view(np.uint32))
     close, exact = (err < 1e-3).mean(), (err == 0).mean()
     mean_ok = abs(got.mean() - want.mean()) <= 0.02 * max(want.mean(), 1e-6)
-    fine = ok_ps and close >= 0.99 and mean_ok and np.isfinite(got).all() and (got >= 0).all()
+    fine = ok_ps and close >= 0.995 and exact >= 0.95 and mean_ok and np.isfinite(got).all() and (got >= 0).all()
     print("seed", seed, "kind", kind, sd.name, "tris", sd.n_tris, "%dx%d" % (w, h), "within 1e-3: %.4f" % close, "identical: %.3f" % exact,
           "means %.5g %.5g" % (got.mean(), want.mean()), "positions", ok_ps, "ok" if fine else "DIFFERENT", flush=True)
     if not fine:
