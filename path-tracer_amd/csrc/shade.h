@@ -136,12 +136,15 @@ PTD V3 reflect(V3 w, V3 n) { return -w + (2.0f * dot(w, n)) * n; }  // include/p
 #define PT_LIBM_F64 2  // 0: device library in single precision, 1: device library in double, 2: the kernels below
 #endif
 
-// cos and sin of a float angle in [0, 8]: quadrant by Cody-Waite with pi/2 in two pieces, Taylor polynomials to r^15 / r^14
-// on |r| <= pi/4 (remainders below 5e-17 and 1.1e-15).  Anything else goes to the device library.
+// cos and sin of a float angle: quadrant by Cody-Waite with pi/2 in two pieces (exact up to |x| = 2^18: k * pi/2_hi is
+// formed inside the fma and the difference is representable), Taylor polynomials to r^15 / r^14 on |r| <= pi/4
+// (remainders below 5e-17 and 1.1e-15).  The shading code only forms angles in [0, 2 pi]; larger ones and NaN go to the
+// device library's single-precision functions (kept small on purpose: the general double-precision reduction would
+// sit in k_shade unused and cost it registers).
 PTD void sincos_r(float xf, float& sn, float& cs) {
-    if (!(xf >= 0.0f && xf <= 8.0f)) {
-        sn = float(sin(double(xf)));
-        cs = float(cos(double(xf)));
+    if (!(__builtin_fabsf(xf) <= 0x1p18f)) {
+        sn = sinf(xf);
+        cs = cosf(xf);
         return;
     }
     const double x = double(xf);
@@ -174,12 +177,13 @@ PTD void sincos_r(float xf, float& sn, float& cs) {
 // x^y for finite x > 0 and finite y as 2^(y log2 x): log through 2 atanh((m - 1) / (m + 1)) with the mantissa m in
 // [sqrt(1/2), sqrt(2)) (series to s^20, remainder below 3e-17), 2^f on |f| <= 1/2 by the Taylor series of e^(f ln 2)
 // to degree 13 (remainder below 4e-18); the one rounding to float also produces the denormal results.  Results near
-// overflow, negative bases, -0 and non-finite operands go to the device library.
+// overflow, negative bases, -0 and non-finite operands (none of which the shading code forms) go to the device library's
+// single-precision function.
 // (a real call, not inlined: three inlined copies cost k_shade 56 registers and with them a third of its waves)
 __device__ __attribute__((noinline)) float pow_k(float xf, float yf) {
     const double x = double(xf), y = double(yf);
     if (as_u(xf) == 0u && yf > 0.0f) return 0.0f;  // +0 to a positive power
-    if (!(xf > 0.0f && xf < __builtin_huge_valf() && __builtin_fabsf(yf) < __builtin_huge_valf())) return float(pow(x, y));
+    if (!(xf > 0.0f && xf < __builtin_huge_valf() && __builtin_fabsf(yf) < __builtin_huge_valf())) return powf(xf, yf);
     int e;
     double m = __builtin_frexp(x, &e);
     if (m < 0.70710678118654752440) {
@@ -202,7 +206,7 @@ __device__ __attribute__((noinline)) float pow_k(float xf, float yf) {
     const double l2 = __builtin_fma(ln_m, 1.44269504088896340736, double(e));  // log2 x
     const double w = y * l2;
     if (w < -150.5) return 0.0f;  // below half of the smallest denormal
-    if (!(w < 127.0)) return float(pow(x, y));
+    if (!(w < 127.0)) return powf(xf, yf);
     const double n = __builtin_rint(w);
     const double t = (w - n) * 0.69314718055994530942;
     double q = 1.0 / 6227020800.0;
