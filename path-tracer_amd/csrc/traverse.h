@@ -269,8 +269,9 @@ PTD bool tri_hit(V3 p0, V3 e1, V3 e2, const V3& o, const V3& d, float min_dis, f
 // it tries the triangles.  Everything above the leaf is navigation, for which any test that never skips a box the
 // reference accepts (and that can hold an acceptable triangle) will do.
 //
-// Navigation nodes (DevScene::qnodes): a 4-wide tree collapsed from the reference's binary tree (a node's slots are its
-// grandchildren, or a child itself where that child is a leaf), one 64-byte record per node: per slot the box as 16-bit
+// Navigation nodes (DevScene::qnodes): a 4-wide tree collapsed from the reference's binary tree (a node's slots start as
+// its two children; the interior slot with the largest surface is opened into its own children until there are four
+// slots or only leaves are left), one 64-byte record per node: per slot the box as 16-bit
 // coordinates on a grid over the scene bounds (origin q_org, spacing q_step per axis), rounded outwards by at least one
 // grid step, and the reference of the slot's subtree:
 //      4 x {c.x, c.y, c.z, ref},   c.x = lo.x | hi.x << 16  etc.,  ref = kEmptyRef for an unused slot.
