@@ -177,6 +177,8 @@ typedef struct pt_stats {
     double   kernel_ms[PT_MAX_KERNEL_STATS];
     uint64_t kernel_launches[PT_MAX_KERNEL_STATS];
 } pt_stats;
+/* indices into kernel_ms / kernel_launches; PT_K_FINISH = the one launch that runs the last few paths of a pass (chains of
+ * specular bounces beyond max_bounce iterations) to their end */
 enum { PT_K_GENERATE = 0, PT_K_EXTEND = 1, PT_K_SHADE = 2, PT_K_SHADOW = 3, PT_K_FILM = 4, PT_K_RETRACE = 5, PT_K_FINISH = 6 };
 
 typedef struct pt_hip_scene pt_hip_scene;
