@@ -99,6 +99,11 @@ PTD bool last_block_of_shard(uint32_t* done, uint32_t shard) {
 #ifndef WPE_GEN
 #define WPE_GEN 5
 #endif
+// the occlusion query carries no hit record and no distances: 72 registers without spilling, and a seventh wave per SIMD
+// is worth 6 % there (the closest-hit kernel spills 36 registers at 7 and loses 3 %)
+#ifndef WPE_SHADOW
+#define WPE_SHADOW 7
+#endif
 constexpr uint32_t kMaxWaveBlocks = 8;  // workgroups per shard of the wave-refill kernels: between 2 and 8, see wave_blocks()
 constexpr uint32_t kMinWaveBlocks = 2;
 constexpr uint32_t kShadeBlocks = 8;  // most workgroups per shard of k_shade (256 threads each), see shade_blocks()
@@ -501,7 +506,7 @@ struct ShadowIo {
 };
 
 template <class C, class Lane>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_shadow_wave(DevScene sc, ShadowIo io, uint32_t* fetch,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE_SHADOW, WPE_SHADOW))) void k_shadow_wave(DevScene sc, ShadowIo io, uint32_t* fetch,
                                                                                                     uint32_t* done, uint32_t* misc) {
     __shared__ uint32_t s_stack[wave_lds_words<Lane>()];
     const uint32_t shard = shard_index();

@@ -21,7 +21,7 @@
 //
 // Per-lane traversal stack: the first kLdsDepth entries live in LDS, laid out [entry][lane] so that a wave's 64 lanes
 // hit 64 consecutive banks; deeper entries spill to a private (scratch) array.  The host rejects trees deeper than
-// kLdsDepth + kSpillDepth.
+// kMaxStack entries.
 #pragma once
 
 #include "scene_dev.h"
@@ -29,12 +29,14 @@
 namespace ptd {
 
 constexpr int kBlock = 128;      // threads per workgroup of every traversal kernel
+// 20 rows = 10 KB of LDS per workgroup: 14 workgroups (7 waves per SIMD, what the shadow kernel is built for) fit into
+// the 160 KB of a CU; measured against 24 rows at 6 waves per SIMD: no difference.
 #ifndef PT_LDS_DEPTH
-#define PT_LDS_DEPTH 24
+#define PT_LDS_DEPTH 20
 #endif
 constexpr int kLdsDepth = PT_LDS_DEPTH;    // stack entries per lane in LDS
-constexpr int kSpillDepth = 72;  // further entries per lane in scratch
-constexpr int kMaxStack = kLdsDepth + kSpillDepth;
+constexpr int kMaxStack = 96;              // deepest stack a traversal may need (the host rejects deeper trees)
+constexpr int kSpillDepth = kMaxStack - kLdsDepth;  // further entries per lane in scratch
 
 // Explicit address spaces: with generic pointers the compiler merges the two arms of pop() into one flat load.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -109,10 +111,10 @@ struct DistStackN {
 
 // LDS rows of the ordered traversals' stacks (closest hit: references and entry distances, kDistRows each)
 #ifndef PT_DIST_ROWS
-#define PT_DIST_ROWS 12
+#define PT_DIST_ROWS 10
 #endif
 #ifndef PT_ANY_ROWS
-#define PT_ANY_ROWS 24
+#define PT_ANY_ROWS 20
 #endif
 constexpr int kDistRows = PT_DIST_ROWS;
 constexpr int kAnyRows = PT_ANY_ROWS;
