@@ -306,6 +306,12 @@ class Scene:
         _chk(hip_lib().pt_hip_intersect_device(self.h, C.c_void_p(d_rays_ptr), n, C.c_void_p(d_hits_ptr), mode, C.byref(ms)))
         return ms.value
 
+    def occluded_device(self, d_rays_ptr, n, d_occluded_ptr, mode=TRAVERSE_FAST):
+        """Occlusion flags (one byte each) of n pt_ray records at device address d_rays_ptr; returns the kernel time in ms."""
+        ms = C.c_float(0.0)
+        _chk(hip_lib().pt_hip_occluded_device(self.h, C.c_void_p(d_rays_ptr), n, C.c_void_p(d_occluded_ptr), mode, C.byref(ms)))
+        return ms.value
+
     def occluded(self, rays, mode=TRAVERSE_EXACT):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         occ = np.zeros(len(rays), np.uint8)
