@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Prepends the derived figures of the 49 M triangle / 3840x2160 profile (tools/gpu_uhd_prof.sh) to its text summary and
+writes profiles/r2_<letter>_rocprof_pmc_library49M_uhd_fast.txt.
+Usage: tools/uhd_summary.py <tag> <letter> <Mrays/s outside the profiler>"""
+import os, re, sys
+tag, letter, mrays = sys.argv[1:4]
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = open(os.path.join(R, "gpurun_out", tag + "_prof.txt")).read()
+c = {}
+calls = dur = None
+for sec in src.split("== ")[1:]:
+    lines = sec.split("\n")
+    if lines[0].startswith("rocprofv3 --kernel-trace"):
+        for l in lines[2:]:
+            if l.startswith("k_extend_wave"):
+                f = l.split()
+                calls, dur = int(f[1]), float(f[2]) / 1e3
+                break
+        continue
+    names = lines[1].split()[2:]
+    for l in lines[2:]:
+        if l.startswith("k_extend_wave"):
+            for k, v in zip(names, l.split()[2:]):
+                c.setdefault(k, float(v))
+            break
+ref = os.path.join(R, "profiles", "r2_%s_rocprof_pmc_library512spp_fast.txt" % letter)
+paths = re.search(r"(\d+) rays", src)
+cyc = c["GRBM_GUI_ACTIVE"] / 8
+issue = c["SQ_INSTS_VALU"] * 2 / (1024 * cyc)
+hit = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+gb = (c["TCC_EA0_RDREQ_sum"] + c["TCC_EA0_WRREQ_sum"]) * 64 / 1e9
+hdr = """# library-synth at 49 M triangles (detail 44), 3840x2160, 16 spp in one pass, ordered traversal -- the largest configuration's
+# per-GPU shape.  Command: bash tools/gpu_uhd_prof.sh %s "library-synth@44:3840x2160" 16  (kernel trace, then one rocprofv3
+# --pmc run per counter group, each of the same short render; kernels of the commit that adds this file), summarised by
+# tools/uhd_summary.py.  Throughput of the same scene and frame size outside the profiler: %s Mrays/s at 64 spp per pass
+# (tools/gpu_pass.py; round 1: 2218).
+#
+# k_extend_wave (%d launches, %.1f ms); the 1.64 M triangle / 1280x720 case for comparison is %s:
+#   VALU issue          SQ_INSTS_VALU x 2 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)  = %.4g x 2 / (1024 x %.4g) = %.3f
+#                       (a CDNA4 SIMD issues a wave64 instruction per 2 cycles; at the 4 cycles a single wave sustains: %.2f)
+#   waves waiting       SQ_WAIT_ANY / SQ_WAVE_CYCLES                            = %.4g / %.4g = %.2f
+#   lanes per VALU op   SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)      = %.4g / (64 x %.4g) = %.2f
+#   L2 hit rate         TCC_HIT / (TCC_HIT + TCC_MISS)                          = %.4g / %.4g = %.2f
+#   fabric traffic      (TCC_EA0_RDREQ + TCC_EA0_WRREQ) x 64 B / duration       = %.0f GB / %.4f s = %.2f TB/s = %.2f of HBM peak
+#   L2 read latency     TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ             = %.4g / %.4g = %.0f cycles per request
+#   address translation TCP_UTCL1_TRANSLATION_MISS / (HIT + MISS)               = %.4g / %.4g = %.3f
+""" % (tag, mrays, calls, dur, os.path.relpath(ref, R), c["SQ_INSTS_VALU"], cyc, issue, 2 * issue, c["SQ_WAIT_ANY"], c["SQ_WAVE_CYCLES"],
+       c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], c["SQ_THREAD_CYCLES_VALU"], c["SQ_ACTIVE_INST_VALU"], c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"]),
+       c["TCC_HIT_sum"], c["TCC_HIT_sum"] + c["TCC_MISS_sum"], hit, gb, dur / 1e3, gb / dur, gb / dur / 8.0,
+       c["TCP_TCC_READ_REQ_LATENCY_sum"], c["TCP_TCC_READ_REQ_sum"], c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"],
+       c["TCP_UTCL1_TRANSLATION_MISS_sum"], c["TCP_UTCL1_TRANSLATION_HIT_sum"] + c["TCP_UTCL1_TRANSLATION_MISS_sum"],
+       c["TCP_UTCL1_TRANSLATION_MISS_sum"] / (c["TCP_UTCL1_TRANSLATION_HIT_sum"] + c["TCP_UTCL1_TRANSLATION_MISS_sum"]))
+hdr += """# Reading: the drop between 1.6 M and 49 M triangles is not an HBM-bandwidth limit (even if the 64-byte gather counters read
+# 2x low).  Two things add up: the tree is five binary levels deeper and the rays less coherent relative to it, so a path
+# costs 1.5x the traversal instructions at fewer lanes per instruction; and every second L2 request misses, which six waves
+# per SIMD cover even less: the VALU issue share falls by a quarter.
+"""
+out = os.path.join(R, "profiles", "r2_%s_rocprof_pmc_library49M_uhd_fast.txt" % letter)
+open(out, "w").write(hdr + src)
+print(hdr)
