@@ -33,7 +33,7 @@ hdr = """# library-synth at 49 M triangles (detail 44), 3840x2160, 16 spp in one
 # per-GPU shape.  Command: bash tools/gpu_uhd_prof.sh %s "library-synth@44:3840x2160" 16  (kernel trace, then one rocprofv3
 # --pmc run per counter group, each of the same short render; kernels of the commit that adds this file), summarised by
 # tools/uhd_summary.py.  Throughput of the same scene and frame size outside the profiler: %s Mrays/s at 64 spp per pass
-# (tools/gpu_pass.py; round 1: 2218).
+# (tools/gpu_pass.py).
 #
 # k_extend_wave (%d launches, %.1f ms); the 1.64 M triangle / 1280x720 case for comparison is %s:
 #   VALU issue          SQ_INSTS_VALU x 2 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)  = %.4g x 2 / (1024 x %.4g) = %.3f
