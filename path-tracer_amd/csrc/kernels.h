@@ -793,37 +793,48 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq
 
 // ------------------------------------------------------------------------------------------------ finish
 
-// The remaining iterations of a few paths in one launch.  A specular bounce is not counted (src/integrator.cpp:84-87), so
-// once every path has had maxBounce iterations only chains of mirror reflections are left -- often a handful of paths
-// that go on for thousands of iterations (a mirror with interpolated normals reflects rays below its own surface, and
-// such a path creeps along a crease).  Three launches and a counter read-back per iteration would be all overhead then.
-// Here one wave takes one path -- entry `j` of the hit list of shard `shard`, both from `entries` -- and its first lane
-// runs shade, visibility test and next intersection, all in the reference's visit order, until the path ends: a chain of
-// dependent memory accesses either way, and a wave to itself keeps it free of divergence (paths in the lanes of one wave
-// are in different phases all the time; measured 18 us per iteration against 4).  misc[16..19] receive the numbers of
-// closest-hit and any-hit queries as two 64-bit totals.
+// Up to `budget` further iterations of a few paths in one launch.  Two situations call for it.  (1) The tail of every
+// pass: Russian roulette thins the paths out quickly (after ten bounces one in two thousand is left), but every further
+// bounce still costs three launches whose time no longer depends on how little they carry -- a tenth of a pass went into
+// its last twenty bounces.  (2) A specular bounce is not counted (src/integrator.cpp:84-87), so once every path has had
+// maxBounce iterations only chains of mirror reflections are left, often a handful of paths that go on for thousands of
+// iterations (a mirror with interpolated normals reflects rays below its own surface, and such a path creeps along a
+// crease).
+// Here the first `lanes` lanes of a wave take one path each -- entry `j` of the hit list of shard `shard`, both from
+// `entries` -- and run shade, visibility test and next intersection, all in the reference's visit order, until the path
+// ends: a chain of dependent memory accesses either way.  Paths in the lanes of one wave are in different phases all the
+// time, so few lanes per wave keep the iteration short (measured: 10 us per iteration with one path per wave, 18 us
+// with 64): one for the long chains, four for the tail of a pass, where the number of paths the chip holds at once
+// counts for more.  A path that is still alive when the
+// budget is used up goes back to its shard: its state to path queue `out`, its pending hit to hit list `hq_out`, as the
+// shade and extend kernels would have left them.  misc[16..19] receive the numbers of closest-hit and any-hit queries
+// as two 64-bit totals (without the pending hits that go back: those are counted with the queue they go to).
 constexpr int kFinishBlock = 64;
 template <class C>
-__global__ __launch_bounds__(kFinishBlock) void k_finish(DevScene sc, PassArgs pa, HitQ hq, PathQ q, const uint2* entries, float4* lbuf,
-                                                         uint32_t max_iterations, uint32_t* misc) {
+__global__ __launch_bounds__(kFinishBlock) void k_finish(DevScene sc, PassArgs pa, HitQ hq, PathQ q, PathQ out, HitQ hq_out, const uint2* entries,
+                                                         uint32_t n_entries, uint32_t lanes, float4* lbuf, uint32_t budget, uint32_t* misc) {
     __shared__ uint32_t s_stack[kLdsDepth * kBlock];  // the stack's rows are kBlock words apart
-    const uint2 e = entries[blockIdx.x];
+    const uint32_t ei = blockIdx.x * lanes + threadIdx.x;
+    const bool mine = threadIdx.x < lanes && ei < n_entries;
+    const uint2 e = mine ? entries[ei] : make_uint2(0u, 0xffffffffu);
     const size_t sbase = size_t(e.x) * kShard;
     C wce, wcs;
     uint32_t n_closest = 0, n_any = 0;
-    if (threadIdx.x == 0 && e.y < hq.count[e.x]) {
+    uint32_t* const my_stack = s_stack + threadIdx.x;
+    if (mine && e.y < hq.count[e.x]) {
         float4 h0 = hq.h0[sbase + e.y], h1 = hq.h1[sbase + e.y];
         const size_t pi = sbase + as_u(h0.x);
         float4 a = q.a[pi], b = q.b[pi], c = q.c[pi];
         const uint32_t slot = q.slot[pi];
-        for (uint32_t it = 0; it < max_iterations; ++it) {
+        bool alive = true;
+        for (uint32_t it = 0; it < budget; ++it) {
             ShadeOut o;
             shade_hit(sc, pa, h0, h1, a, b, c, slot, lbuf, o);
             if (o.want_shadow) {
                 const RayD sr{V3{o.sa.x, o.sa.y, o.sa.z}, V3{o.sa.w, o.sb.x, o.sb.y}, 0.0f, o.sb.z};
                 int32_t first_prim;
                 ++n_any;
-                if (!any_exact(sc, sr, first_prim, s_stack, wcs)) {
+                if (!any_exact(sc, sr, first_prim, my_stack, wcs)) {
                     float4 L = lbuf[slot];
                     L.x += o.sc4.x;
                     L.y += o.sc4.y;
@@ -831,16 +842,29 @@ __global__ __launch_bounds__(kFinishBlock) void k_finish(DevScene sc, PassArgs p
                     lbuf[slot] = L;
                 }
             }
+            alive = false;
             if (!o.cont) break;
             const RayD ray{V3{o.na.x, o.na.y, o.na.z}, V3{o.na.w, o.nb.x, o.nb.y}, 0.0f, __builtin_huge_valf()};
             HitD h;
             ++n_closest;
-            if (!closest_exact(sc, ray, h, s_stack, wce)) break;
+            if (!closest_exact(sc, ray, h, my_stack, wce)) break;
+            alive = true;
             a = o.na;
             b = o.nb;
             c = o.nc;
             h0 = make_float4(0.0f, as_f(uint32_t(h.prim)), h.u, h.v);
             h1 = make_float4(c.z, c.w, h.t, 0.0f);
+        }
+        if (alive) {
+            const uint32_t nl = atomicAdd(out.count + e.x, 1u);
+            out.a[sbase + nl] = a;
+            out.b[sbase + nl] = b;
+            out.c[sbase + nl] = c;
+            out.slot[sbase + nl] = slot;
+            const uint32_t hl = atomicAdd(hq_out.count + e.x, 1u);
+            hq_out.h0[sbase + hl] = make_float4(as_f(nl), h0.y, h0.z, h0.w);
+            hq_out.h1[sbase + hl] = h1;
+            --n_closest;
         }
         atomicAdd(reinterpret_cast<unsigned long long*>(misc + 16), (unsigned long long)n_closest);
         atomicAdd(reinterpret_cast<unsigned long long*>(misc + 18), (unsigned long long)n_any);

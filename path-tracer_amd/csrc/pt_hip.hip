@@ -121,6 +121,17 @@ constexpr int kRing = 4;  // counter snapshots in flight between the stream and 
 // x 8 waves at that kernel's register count).  More paths than that are better off in the regular loop, whose cost per
 // iteration does not depend on their number.
 constexpr uint32_t kFinishPaths = 2048;
+// The tail of a pass (ordinary paths, at most max_bounce iterations each) goes to k_finish once at most this many paths
+// are alive, but not before the first kTailStart bounces have gone through the regular kernels.
+// Measured on 128- and 512-spp passes of the 1.6 M triangle interior / veach-mis: 8192 paths +1.3 / +3.2 %, 16384
+// +1.6 / +3.3 %, 32768 with four paths per wave +1.9 / +3.8 %, 131072 (four or eight per wave) +1.2 / +3.7 %, 524288
+// -4 %: k_finish lasts as long as its longest path, and beyond what the chip holds at once it queues.
+#ifndef PT_TAIL_PATHS
+#define PT_TAIL_PATHS 32768
+#endif
+constexpr uint32_t kTailPaths = PT_TAIL_PATHS;
+constexpr uint32_t kTailStart = 6;
+constexpr uint32_t kTailLanes = 4;
 
 struct Workspace {
     uint32_t cap_slots = 0;   // padded to whole shards
@@ -144,7 +155,7 @@ struct Workspace {
     hipEvent_t ring_ev[kRing] = {};
     uint32_t* frame_tab = nullptr;
     size_t frame_cap = 0;  // in frames
-    uint2* finish_list = nullptr;  // (shard, hit-list entry) pairs handed to k_finish (kFinishPaths of them)
+    uint2* finish_list = nullptr;  // (shard, hit-list entry) pairs handed to k_finish (max(kFinishPaths, kTailPaths) of them)
     std::vector<void*> owned;
     size_t misc_offset() const { return (size_t(11) * n_shards + 1) & ~size_t(1); }  // 64-bit atomics live in misc: keep it 8-byte aligned
     size_t counter_words() const { return misc_offset() + kMiscWords; }
@@ -719,7 +730,7 @@ int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
         if (int rc = ws_alloc(ws, &ws.lbuf, padded)) return rc;
         if (int rc = ws_alloc(ws, &ws.counters, ws.counter_words())) return rc;
         if (int rc = ws_alloc(ws, &ws.frame_tab, n_frames * 1024)) return rc;
-        if (int rc = ws_alloc(ws, &ws.finish_list, kFinishPaths)) return rc;
+        if (int rc = ws_alloc(ws, &ws.finish_list, std::max(kFinishPaths, kTailPaths))) return rc;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ws.h_counters), (size_t(kRing) * ws.snapshot_words() + kMiscWords) * sizeof(uint32_t),
                               hipHostMallocDefault));
         for (hipEvent_t& e : ws.ring_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -865,6 +876,8 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
     const bool fast = pa.traversal == PT_TRAVERSE_FAST;
     uint32_t bound = std::min<uint32_t>(kShard, pa.n_slots);  // upper bound of every shard fill from here on
     bool finished = false;
+    bool tail_done = false;
+    uint64_t finish_closest = 0, finish_any = 0;  // k_finish's query totals read so far in this pass
     uint64_t live = ~0ull;                 // paths alive after the latest snapshot read
     const uint32_t* live_counts = nullptr;  // ... per shard (in the pinned ring: valid until kRing more snapshots are queued)
     uint32_t launched = 0, consumed = 0;  // snapshots queued / read; snapshot i describes bounce i (taken after its shade)
@@ -901,32 +914,53 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
     for (uint32_t iter = 0; iter < kMaxIterations; ++iter) {
         if (int rc = consume(true)) return rc;  // the previous bounce's snapshot
         if (finished) break;
-        if (iter >= pa.max_bounce && live <= kFinishPaths) {
+        // k_finish takes over (see there): for good once only chains of specular bounces are left and few of them, or once
+        // per pass for up to max_bounce iterations when Russian roulette has thinned the paths out -- what is alive after
+        // that (specular chains again) comes back to the queues and the loop goes on with it.  List-mode calls (pt_hip_li)
+        // keep to the regular kernels for the tail: they are how single samples of those kernels are checked.
+        const bool chains = iter >= pa.max_bounce && live <= kFinishPaths;
+        const bool tail = !tail_done && pa.list_xy == nullptr && iter >= kTailStart && live <= kTailPaths;
+        if (chains || tail) {
             // `launched == consumed` here: live_counts describes the queue that the hit list of this iteration came from
             // (a shard's hit list is at most as long as the path queue it came from)
             std::vector<uint2> list;
             for (uint32_t k = 0; k < K; ++k)
                 for (uint32_t j = 0; j < live_counts[k]; ++j) list.push_back(make_uint2(k, j));
-            const int cur = int(iter & 1u);
+            const int cur = int(iter & 1u), nxt = cur ^ 1;
             ws.hq.count = ws.hit_count[cur];
+            HitQ hq_next = ws.hq;
+            hq_next.count = ws.hit_count[nxt];
             HIP_TRY(hipMemcpyAsync(ws.finish_list, list.data(), list.size() * sizeof(uint2), hipMemcpyHostToDevice, g_stream));
+            // the counters as the shade and extend kernels of this iteration would have left them, bar the paths that
+            // come back: those are appended by k_finish
+            for (uint32_t* p : {ws.q[cur].count, hq_next.count, ws.fetch_e, ws.dqe.count, ws.done_e}) HIP_TRY(hipMemsetAsync(p, 0, K * sizeof(uint32_t), g_stream));
             if (int rc = tm.begin(PT_K_FINISH)) return rc;
-            const uint32_t left = kMaxIterations - iter;
+            const uint32_t budget = chains ? kMaxIterations - iter : pa.max_bounce;
+            const uint32_t lanes = chains ? 1u : kTailLanes;  // paths per wave
             if (count)
-                hipLaunchKernelGGL(k_finish<Count>, dim3(uint32_t(list.size())), dim3(kFinishBlock), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.finish_list, ws.lbuf,
-                                   left, ws.misc);
+                hipLaunchKernelGGL(k_finish<Count>, dim3(blocks(uint32_t(list.size()), lanes)), dim3(kFinishBlock), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.q[nxt], hq_next,
+                                   ws.finish_list, uint32_t(list.size()), lanes, ws.lbuf, budget, ws.misc);
             else
-                hipLaunchKernelGGL(k_finish<NoCount>, dim3(uint32_t(list.size())), dim3(kFinishBlock), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.finish_list,
-                                   ws.lbuf, left, ws.misc);
+                hipLaunchKernelGGL(k_finish<NoCount>, dim3(blocks(uint32_t(list.size()), lanes)), dim3(kFinishBlock), 0, g_stream, s->dev, pa, ws.hq, ws.q[cur], ws.q[nxt], hq_next,
+                                   ws.finish_list, uint32_t(list.size()), lanes, ws.lbuf, budget, ws.misc);
             if (int rc = tm.end()) return rc;
             uint32_t* h = ws.h_misc() + 16;
             HIP_TRY(hipMemcpyAsync(h, ws.misc + 16, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+            // this iteration's snapshot: the paths that came back
+            HIP_TRY(hipMemcpyAsync(ws.h_counters + size_t(launched % kRing) * snap, ws.counters, snap * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+            HIP_TRY(hipEventRecord(ws.ring_ev[launched % kRing], g_stream));
+            ++launched;
             HIP_TRY(hipStreamSynchronize(g_stream));  // `list` must outlive its copy, and the totals are read now
+            const uint64_t fc = uint64_t(h[0]) | (uint64_t(h[1]) << 32), fa = uint64_t(h[2]) | (uint64_t(h[3]) << 32);
             if (st) {
-                st->closest_rays += uint64_t(h[0]) | (uint64_t(h[1]) << 32);
-                st->any_rays += uint64_t(h[2]) | (uint64_t(h[3]) << 32);
+                st->closest_rays += fc - finish_closest;  // the totals run over the pass
+                st->any_rays += fa - finish_any;
             }
-            break;
+            finish_closest = fc;
+            finish_any = fa;
+            if (chains) break;
+            tail_done = true;
+            continue;
         }
         if (iter != 0 && iter % 256u == 0) {  // long chains: fold the timing events in now instead of keeping three pairs per iteration
             HIP_TRY(hipStreamSynchronize(g_stream));
