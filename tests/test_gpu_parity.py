@@ -554,6 +554,34 @@ def test_mirror_chains_of_thousands_of_reflections_are_followed_to_the_end():
     g.close()
 
 
+def test_tail_of_a_pass_in_one_launch_and_the_paths_that_outlive_it():
+    """A render hands the thinned-out tail of a pass to one launch (k_finish) for up to maxBounce iterations per path; what
+    is still alive then -- chains of specular bounces, here on the mirror pyramid -- goes back to the queues, the regular
+    kernels carry on with it, and the last few chains end in a second such launch.  The list-mode entry point runs the same
+    samples through the regular kernels alone (plus the final launch): both must trace the same paths, ray for ray, and the
+    film must be the oracle's up to the few chains that leave their crease at another angle."""
+    sd = synth.textured_room(width=40, height=50)
+    sd.mat_ks[sd.mat_names.index("pyr")] = 1000.0
+    o, g = orc.Scene(sd), api.Scene(sd)
+    spp = 16
+    film, st = g.render(0, spp, traversal=api.TRAVERSE_FAST)
+    assert st["kernel_launches"]["finish"] == 2 and st["kernel_launches"]["shade"] > 10   # the regular kernels resumed after the first
+    ys, xs, ss = np.meshgrid(np.arange(sd.height), np.arange(sd.width), np.arange(spp), indexing="ij")
+    xy = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+    _, _, st_li = g.li(xy, ss.ravel().astype(np.uint32), traversal=api.TRAVERSE_FAST)
+    assert st_li["kernel_launches"]["finish"] == 1
+    assert (st["closest_rays"], st["any_rays"]) == (st_li["closest_rays"], st_li["any_rays"])
+    film_exact, st_exact = g.render(0, spp, traversal=api.TRAVERSE_EXACT)
+    assert (st_exact["closest_rays"], st_exact["any_rays"]) == (st["closest_rays"], st["any_rays"])
+    assert np.allclose(film_exact, film, rtol=1e-5, atol=1e-6)
+    want, ost = o.render(0, spp, orc.INTEGRATOR_PATH)
+    got_img, want_img = api.film_to_image(film), api.film_to_image(want)
+    assert abs(got_img.mean() - want_img.mean()) < 1e-3 * want_img.mean()                   # measured 3e-5
+    assert (np.abs(got_img - want_img).max(2) < 1e-3 * (want_img.max(2) + 1e-2)).mean() > 0.97  # measured 0.99
+    assert abs(st["closest_rays"] - ost["closest_rays"]) < 5e-3 * ost["closest_rays"]       # measured 4e-4
+    g.close()
+
+
 def test_ultra_hd_frame_uses_the_4096_wide_sobol_grid():
     """3840x2160 needs the 2^12 pixel grid of SobolSampler (scale = roundUpPow2(max(W, H)), src/sampler.cpp:89-100): Sobol'
     values and film positions bit-exact, per-sample radiance and a one-sample AOV film against the oracle."""
