@@ -131,6 +131,11 @@ constexpr uint32_t kFinishPaths = 2048;
 #endif
 constexpr uint32_t kTailPaths = PT_TAIL_PATHS;
 constexpr uint32_t kTailStart = 6;
+// The paths of a pass are gathered into a few dense shards once they are at most 1 / kCompactShare of its slots.
+#ifndef PT_COMPACT_SHARE
+#define PT_COMPACT_SHARE 32
+#endif
+constexpr uint64_t kCompactShare = PT_COMPACT_SHARE;
 constexpr uint32_t kTailLanes = 4;
 
 struct Workspace {
@@ -705,6 +710,24 @@ void ws_release(Workspace& ws) {
     ws = Workspace();
 }
 
+// the eleven per-shard counter arrays for K shards in play, back to back at the start of ws.counters (ws.misc stays where
+// ws_reserve put it: behind the arrays of the pass's full shard count)
+void ws_layout(Workspace& ws, uint32_t n_shards) {
+    const size_t K = n_shards;
+    ws.q[0].count = ws.counters;
+    ws.q[1].count = ws.counters + K;
+    ws.hit_count[0] = ws.counters + 2 * K;
+    ws.hit_count[1] = ws.counters + 3 * K;
+    ws.hq.count = ws.hit_count[0];
+    ws.sh.count = ws.counters + 4 * K;
+    ws.fetch_e = ws.counters + 5 * K;
+    ws.fetch_s = ws.counters + 6 * K;
+    ws.dqe.count = ws.counters + 7 * K;
+    ws.dqs.count = ws.counters + 8 * K;
+    ws.done_e = ws.counters + 9 * K;
+    ws.done_s = ws.counters + 10 * K;
+}
+
 int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
     uint32_t n_shards = (n_slots + kShard - 1) / kShard;
     const uint32_t gz = (n_shards + kMaxGridY - 1) / kMaxGridY;
@@ -739,20 +762,8 @@ int ws_reserve(Workspace& ws, uint32_t n_slots, size_t n_frames) {
     }
     // a smaller request reuses the buffers with fewer shards in play; counters are laid out for this request
     ws.n_shards = n_shards;
-    const size_t K = n_shards;
-    ws.q[0].count = ws.counters;
-    ws.q[1].count = ws.counters + K;
-    ws.hit_count[0] = ws.counters + 2 * K;
-    ws.hit_count[1] = ws.counters + 3 * K;
-    ws.hq.count = ws.hit_count[0];
-    ws.sh.count = ws.counters + 4 * K;
-    ws.fetch_e = ws.counters + 5 * K;
-    ws.fetch_s = ws.counters + 6 * K;
-    ws.dqe.count = ws.counters + 7 * K;
-    ws.dqs.count = ws.counters + 8 * K;
-    ws.done_e = ws.counters + 9 * K;
-    ws.done_s = ws.counters + 10 * K;
     ws.misc = ws.counters + ws.misc_offset();
+    ws_layout(ws, n_shards);
     return PT_OK;
 }
 
@@ -871,12 +882,14 @@ constexpr uint32_t kMaxIterations = 1u << 20;  // of the bounce loop, per pass
 // fills cost a lot -- a workgroup that finds nothing to do still takes ~0.2 us of dispatch (scratch + 12 KB LDS).
 int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bool count) {
     Workspace& ws = s->ws;
-    const uint32_t K = ws.n_shards;
-    const size_t snap = ws.snapshot_words();
+    uint32_t K = ws.n_shards;          // shards in play: all of the pass's until the paths are gathered into a few (below)
+    size_t snap = ws.snapshot_words();
+    bool compacted = false;            // once per pass (k_compact's position counter starts at zero with the pass)
     const bool fast = pa.traversal == PT_TRAVERSE_FAST;
     uint32_t bound = std::min<uint32_t>(kShard, pa.n_slots);  // upper bound of every shard fill from here on
     bool finished = false;
     bool tail_done = false;
+    bool regrouped = false;  // the snapshot about to be read lists paths a second time (in their new shards after k_compact): not new rays
     uint64_t finish_closest = 0, finish_any = 0;  // k_finish's query totals read so far in this pass
     uint64_t live = ~0ull;                 // paths alive after the latest snapshot read
     const uint32_t* live_counts = nullptr;  // ... per shard (in the pinned ring: valid until kRing more snapshots are queued)
@@ -894,10 +907,11 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
             const uint32_t* c = ws.h_counters + size_t(consumed % kRing) * snap;
             const int nxt = int(consumed & 1u) ^ 1;
             const Fill next = fill_of(c + size_t(nxt) * K, K), shadow = fill_of(c + 4 * size_t(K), K);
-            if (st) {
+            if (st && !regrouped) {
                 st->any_rays += shadow.sum;
                 st->closest_rays += next.sum;
             }
+            regrouped = false;
             bound = std::min(bound, std::max(next.max, 1u));
             if (next.max == 0) finished = true;
             live = next.sum;
@@ -914,6 +928,37 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
     for (uint32_t iter = 0; iter < kMaxIterations; ++iter) {
         if (int rc = consume(true)) return rc;  // the previous bounce's snapshot
         if (finished) break;
+        // Russian roulette has left a small share of the paths, a few per shard: gather them into the first shards (k_compact)
+        // and go on with those.  The counter arrays are laid out anew for the smaller shard count at the start of the
+        // counter block; the old hit counts, which k_compact reads, lie behind that (11 Kc <= 2 K).  The gathered hit list
+        // goes into the shadow queue's buffers (free between two bounces), which then swap roles with the hit list's.
+        {
+            const uint32_t Kc = uint32_t((live + kShard - 1) / kShard);
+            if (!compacted && pa.list_xy == nullptr && iter >= 1 && live > kTailPaths && live * kCompactShare <= pa.n_slots && size_t(11) * Kc <= size_t(2) * K) {
+                const int cur = int(iter & 1u), nxt = cur ^ 1;
+                HitQ hq_old = ws.hq;
+                hq_old.count = ws.hit_count[cur];
+                const PathQ q_old = ws.q[cur];
+                HIP_TRY(hipMemsetAsync(ws.counters, 0, size_t(11) * Kc * sizeof(uint32_t), g_stream));
+                ws_layout(ws, Kc);
+                if (int rc = tm.begin(PT_K_COMPACT)) return rc;
+                hipLaunchKernelGGL(k_compact, shard_grid(1, K), dim3(256), 0, g_stream, hq_old, q_old, ws.q[nxt], ws.sh.a, ws.sh.b, ws.misc + 20);
+                hipLaunchKernelGGL(k_dense_counts, dim3(blocks(Kc, 256)), dim3(256), 0, g_stream, ws.misc + 20, ws.q[nxt].count, ws.hit_count[nxt], Kc);
+                if (int rc = tm.end()) return rc;
+                std::swap(ws.hq.h0, ws.sh.a);
+                std::swap(ws.hq.h1, ws.sh.b);
+                K = Kc;
+                snap = size_t(5) * Kc;
+                bound = std::min<uint32_t>(kShard, uint32_t(live));
+                compacted = true;
+                // this iteration's snapshot: the same paths, in their new shards (they are not counted as rays again)
+                HIP_TRY(hipMemcpyAsync(ws.h_counters + size_t(launched % kRing) * snap, ws.counters, snap * sizeof(uint32_t), hipMemcpyDeviceToHost, g_stream));
+                HIP_TRY(hipEventRecord(ws.ring_ev[launched % kRing], g_stream));
+                ++launched;
+                regrouped = true;
+                continue;
+            }
+        }
         // k_finish takes over (see there): for good once only chains of specular bounces are left and few of them, or once
         // per pass for up to max_bounce iterations when Russian roulette has thinned the paths out -- what is alive after
         // that (specular chains again) comes back to the queues and the loop goes on with it.  List-mode calls (pt_hip_li)
@@ -1010,6 +1055,7 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
     }
     if (int rc = consume(true)) return rc;
     HIP_TRY(hipGetLastError());
+    ws_layout(ws, ws.n_shards);  // the next pass starts with all shards again
     return PT_OK;
 }
 

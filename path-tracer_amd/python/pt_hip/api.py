@@ -14,7 +14,7 @@ TRAVERSE_EXACT, TRAVERSE_FAST = 0, 1
 FLAG_NO_KERNEL_TIMING, FLAG_COUNT_WORK = 1, 2
 INTEGRATOR_PATH, INTEGRATOR_NORMAL, INTEGRATOR_ALBEDO = 0, 1, 2
 NOALLOC_MAX_RAYS = 67108864      # PT_NOALLOC_MAX_RAYS
-KERNEL_NAMES = ["generate", "extend", "shade", "shadow", "film", "retrace", "finish", "k7"]
+KERNEL_NAMES = ["generate", "extend", "shade", "shadow", "film", "retrace", "finish", "compact"]
 
 c_f32p = C.POINTER(C.c_float)
 c_u32p = C.POINTER(C.c_uint32)
