@@ -131,7 +131,7 @@ struct PassArgs {
 
 // misc[0] = exact re-traces.  Counting builds only: for kernel class k (0 generate, 1 extend, 2 shadow) the u64 at
 // word 4 + 4k holds the node records fetched and the u64 at word 6 + 4k the triangle records fetched.  Words 16..19: the
-// queries of k_finish (two u64).  Word 20: k_compact's position counter.
+// queries of k_finish (two u64).
 constexpr int kMiscWords = 24;
 
 // A ray that a wave-refill kernel handed back, in reference order: the whole query (plain-division rays, kDeferExact), or
@@ -875,32 +875,51 @@ __global__ __launch_bounds__(kFinishBlock) void k_finish(DevScene sc, PassArgs p
 
 // ------------------------------------------------------------------------------------------------ compact
 
-// Once per pass, when Russian roulette has left a small share of the paths: the survivors, a few per shard, are gathered
+// Whenever Russian roulette has left a small share of the paths in play: the survivors, a few per shard, are gathered
 // into the first shards of the other path queue and of a spare hit list, densely, so that the remaining bounces run on
 // a few full shards instead of all of them nearly empty (a launch over 115 000 shards with three rays each costs what
 // it costs to start 115 000 workgroups).  Which shard a path sits in has no bearing on its result: its radiance slot
-// travels with it.  One global counter hands out the new positions, a wave at a time.
-__global__ __launch_bounds__(256) void k_compact(HitQ hq, PathQ q, PathQ q_new, float4* h0_new, float4* h1_new, uint32_t* total) {
+// travels with it.  New positions: an exclusive prefix sum over the shards' hit counts (k_shard_offsets: one workgroup,
+// every thread a contiguous run of shards), so the order of the paths is kept and no counter is contended.
+constexpr int kOffsetsBlock = 1024;
+__global__ __launch_bounds__(kOffsetsBlock) void k_shard_offsets(const uint32_t* counts, uint32_t n_shards, uint32_t* offsets) {
+    __shared__ uint32_t s_sum[kOffsetsBlock];
+    const uint32_t per = (n_shards + kOffsetsBlock - 1) / kOffsetsBlock;
+    const uint32_t lo = min(threadIdx.x * per, n_shards), hi = min(lo + per, n_shards);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += counts[i];
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < kOffsetsBlock; off <<= 1) {  // inclusive scan of the per-thread sums
+        const uint32_t v = threadIdx.x >= uint32_t(off) ? s_sum[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[threadIdx.x] - sum;
+    for (uint32_t i = lo; i < hi; ++i) {
+        offsets[i] = run;
+        run += counts[i];
+    }
+    if (threadIdx.x == kOffsetsBlock - 1) offsets[n_shards] = s_sum[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_compact(HitQ hq, PathQ q, PathQ q_new, float4* h0_new, float4* h1_new, const uint32_t* offsets) {
     const uint32_t shard = shard_index();
     const size_t sbase = size_t(shard) * kShard;
-    const uint32_t n = hq.count[shard];
-    for (uint32_t base = 0; base < n; base += 256u) {
-        const uint32_t j = base + threadIdx.x;
-        const bool valid = j < n;
-        const uint32_t g = wave_alloc(valid, total);
-        if (valid) {
-            const float4 h0 = hq.h0[sbase + j], h1 = hq.h1[sbase + j];
-            const size_t pi = sbase + as_u(h0.x);
-            q_new.a[g] = q.a[pi];
-            q_new.b[g] = q.b[pi];
-            q_new.c[g] = q.c[pi];
-            q_new.slot[g] = q.slot[pi];
-            h0_new[g] = make_float4(as_f(g % kShard), h0.y, h0.z, h0.w);
-            h1_new[g] = h1;
-        }
+    const uint32_t n = hq.count[shard], first = offsets[shard];
+    for (uint32_t j = threadIdx.x; j < n; j += 256u) {
+        const float4 h0 = hq.h0[sbase + j], h1 = hq.h1[sbase + j];
+        const size_t pi = sbase + as_u(h0.x);
+        const uint32_t g = first + j;
+        q_new.a[g] = q.a[pi];
+        q_new.b[g] = q.b[pi];
+        q_new.c[g] = q.c[pi];
+        q_new.slot[g] = q.slot[pi];
+        h0_new[g] = make_float4(as_f(g % kShard), h0.y, h0.z, h0.w);
+        h1_new[g] = h1;
     }
 }
-// fills of the dense shards after k_compact: `total` entries in shards of kShard
+// fills of the dense shards after k_compact: `*total` entries in shards of kShard
 __global__ void k_dense_counts(const uint32_t* total, uint32_t* path_count, uint32_t* hit_count, uint32_t n_shards) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_shards) return;

@@ -380,7 +380,7 @@ def test_path_traced_image_matches_oracle(veach_gpu, veach_oracle):
     img, ref = api.film_to_image(film), orc.film_to_image(want)
     assert helpers.rel_mse(img, ref) < 1e-5
     # a pass of this size gathers its surviving paths into a few dense shards on the way and ends in the tail launch
-    assert st["kernel_launches"].get("compact") == 1 and st["kernel_launches"].get("finish", 0) >= 1
+    assert st["kernel_launches"].get("compact", 0) >= 1 and st["kernel_launches"].get("finish", 0) >= 1
     assert abs(st["closest_rays"] - ost["closest_rays"]) <= 1e-4 * ost["closest_rays"]
     assert abs(st["any_rays"] - ost["any_rays"]) <= 1e-4 * ost["any_rays"]
     fast, _ = veach_gpu.render(0, 16, traversal=api.TRAVERSE_FAST)
