@@ -191,7 +191,7 @@ def main():
     if rank == 0:
         # per-kernel device time from HIP events recorded on the launch stream inside the timed region
         kms = {k: sum(s["kernel_ms"].get(k, 0.0) for s in stats) for k in api.KERNEL_NAMES[:5]}
-        finish_ms = sum(s["kernel_ms"].get("finish", 0.0) for s in stats)   # the tail of every pass in one launch
+        extra_ms = {k: sum(s["kernel_ms"].get(k, 0.0) for s in stats) for k in ("finish", "compact")}   # tail launch, path gathering
         kn = {k: sum(s["kernel_launches"].get(k, 0) for s in stats) for k in api.KERNEL_NAMES[:5]}
         dominant = max(kms, key=kms.get)
         # average BVH records per ray of each traversal kernel from an instrumented (untimed) pass over 8 spp
@@ -232,7 +232,7 @@ def main():
                                        + " + 1 film reduce, tree built once per node") % world},
             "samples_per_s": paths_total / dt,
             "rays_per_path": rays_total / max(paths_total, 1.0),
-            "kernel_ms_per_step": dict({k: v / a.steps for k, v in kms.items()}, finish=finish_ms / a.steps),
+            "kernel_ms_per_step": dict({k: v / a.steps for k, v in kms.items()}, **{k: v / a.steps for k, v in extra_ms.items()}),
             "kernel_launches_per_step": {k: v / a.steps for k, v in kn.items()},
             "bvh_records_per_ray": bvh,
             # The traversal kernels are not bound by HBM: the records they gather are served by L2 / Infinity Cache.  Nor do
