@@ -643,9 +643,9 @@ struct ShadeOut {
 // sampleLd up to the visibility test (src/integrator.cpp:109-141) for one hit: h0 / h1 are its hit-list entry, a / b / c
 // the state of the path that found it, slot its radiance slot (emitted radiance is added there right away).
 //
-// Memory reads are arranged in three dependent levels: (1) the hit-list entry; (2) the path state, the triangle's
-// shading record and the Sobol' window (all addressed from the entry); (3) the record of the light chosen by the first
-// Sobol' value.
+// Memory reads are arranged in dependent levels: (1) the hit-list entry; (2) the path state, the triangle's shading
+// record and the Sobol' window (all addressed from the entry); (3) the record of the light chosen by the first Sobol'
+// value, read by light_sample_at.
 PTD void shade_hit(const DevScene& sc, const PassArgs& pa, const float4 h0, const float4 h1, const float4 a, const float4 b, const float4 c,
                    const uint32_t slot, float4* lbuf, ShadeOut& o) {
     const uint32_t prim = as_u(h0.y);
@@ -657,13 +657,13 @@ PTD void shade_hit(const DevScene& sc, const PassArgs& pa, const float4 h0, cons
     Sampler smp;
     smp.start(sc, pa.frame_tab + size_t(frame) * 1024u, pix & 0xffffu, pix >> 16, int(meta & 1023u));
     // level 3: the light record depends on the first Sobol' value only
-    LightRec lr;
+    const float4* lrec_ptr = nullptr;
     float u1 = 0.0f;
     if (sc.n_lights != 0u) {
         u1 = smp.s1();
         uint32_t li = uint32_t(int(u1 * float(sc.n_lights)));  // include/pt/light.h:58-60
         if (li >= sc.n_lights) li = sc.n_lights - 1u;          // the reference would throw here; clamp instead
-        lr.load(sc, li);
+        lrec_ptr = sc.lrec + size_t(li) * kLightRecVec4;
     }
 
     const V3 ro{a.x, a.y, a.z}, rd{a.w, b.x, b.y};
@@ -696,7 +696,7 @@ PTD void shade_hit(const DevScene& sc, const PassArgs& pa, const float4 h0, cons
     // light sampling (src/integrator.cpp:109-141)
     if (sc.n_lights != 0u) {
         const float selectPdf = 1.0f / float(sc.n_lights);
-        const LiSample ls = light_sample(lr, it.p, it.n, smp.s2());
+        const LiSample ls = light_sample_at(lrec_ptr, it.p, it.n, smp.s2());
         if (ls.pdfDir != 0.0f) {
             // Scene::unocculded (src/scene.cpp:213-220)
             const V3 p0 = it.p + it.n * kEps, p1 = ls.p + ls.n * kEps;
@@ -757,8 +757,8 @@ PTD void shade_hit(const DevScene& sc, const PassArgs& pa, const float4 h0, cons
 }
 
 // shade_hit for every entry of the hit lists: the shadow ray goes to the shadow queue, the continued path to the next
-// path queue.  165 registers, 3 waves per SIMD; capping the registers for a fourth wave spills and is slower (measured:
-// 58 against 42.5 ms per 128-spp pass of the 1.6 M triangle interior), as is a fifth or sixth.
+// path queue.  120 registers, 4 waves per SIMD, thanks to three real calls (pow_k, sincos_call, light_sample_at); capping
+// the registers of the fully inlined code instead spills and is much slower.
 __global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq, PathQ in, PathQ out, ShadowQ sh, float4* lbuf, ZeroList zl) {
     const uint32_t shard = shard_index();
     zero_counters(zl, shard);

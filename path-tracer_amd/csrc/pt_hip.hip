@@ -934,8 +934,13 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
         // counter block; the old hit counts, which k_compact reads, lie behind that (11 Kc <= 2 K).  The gathered hit list
         // goes into the shadow queue's buffers (free between two bounces), which then swap roles with the hit list's.
         {
-            const uint32_t Kc = uint32_t((live + kShard - 1) / kShard);
-            if (pa.list_xy == nullptr && iter >= 1 && live > kTailPaths && live * kCompactShare <= std::min<uint64_t>(pa.n_slots, uint64_t(K) * kShard) &&
+            uint32_t Kc = 0;
+            if (live - 1 < uint64_t(pa.n_slots)) {  // a snapshot has been read and something is alive
+                Kc = uint32_t((live + kShard - 1) / kShard);
+                const uint32_t gz = (Kc + kMaxGridY - 1) / kMaxGridY;
+                Kc = (Kc + gz - 1) / gz * gz;  // whole grid.z layers, as shard_grid expects
+            }
+            if (Kc != 0 && pa.list_xy == nullptr && iter >= 1 && live > kTailPaths && live * kCompactShare <= std::min<uint64_t>(pa.n_slots, uint64_t(K) * kShard) &&
                 size_t(11) * Kc <= size_t(2) * K) {
                 const int cur = int(iter & 1u), nxt = cur ^ 1;
                 HitQ hq_old = ws.hq;

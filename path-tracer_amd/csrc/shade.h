@@ -141,11 +141,20 @@ PTD V3 reflect(V3 w, V3 n) { return -w + (2.0f * dot(w, n)) * n; }  // include/p
 // (remainders below 5e-17 and 1.1e-15).  The shading code only forms angles in [0, 2 pi]; larger ones and NaN go to the
 // device library's single-precision functions (kept small on purpose: the general double-precision reduction would
 // sit in k_shade unused and cost it registers).
+// (a real call returning the pair by value, like pow_k below: with it and the light sampling call k_shade needs 120
+// registers instead of 165 and runs four waves per SIMD instead of three)
+__device__ __attribute__((noinline)) float2 sincos_call(float xf);
 PTD void sincos_r(float xf, float& sn, float& cs) {
+    const float2 r = sincos_call(xf);
+    sn = r.x;
+    cs = r.y;
+}
+__device__ __attribute__((noinline)) float2 sincos_call(float xf) {
+    float sn, cs;
     if (!(__builtin_fabsf(xf) <= 0x1p18f)) {
         sn = sinf(xf);
         cs = cosf(xf);
-        return;
+        return make_float2(sn, cs);
     }
     const double x = double(xf);
     const double k = __builtin_rint(x * 0.63661977236758134308);  // 2 / pi
@@ -172,6 +181,7 @@ PTD void sincos_r(float xf, float& sn, float& cs) {
     const double so = (q & 1) ? c : s, co = (q & 1) ? s : c;
     sn = float((q & 2) ? -so : so);
     cs = float(((q + 1) & 2) ? -co : co);
+    return make_float2(sn, cs);
 }
 
 // x^y for finite x > 0 and finite y as 2^(y log2 x): log through 2 atanh((m - 1) / (m + 1)) with the mantissa m in
@@ -356,6 +366,17 @@ PTD LiSample light_sample(const LightRec& l, V3 sp, V3 sn, V2 u) {
         o.pdfDir = l.inv_area() * dist * dist / cos_lw;
     }
     return o;
+}
+
+// The same as a real call that reads the light's record itself: the record's 24 registers are then held for the length
+// of the call only, not from the moment the light is chosen (the record of one of a few lights comes from the nearest
+// cache; with the sine / cosine call this takes k_shade from 165 to 120 registers, 3 to 4 waves per SIMD: -9 % of its
+// time on the 1.6 M triangle interior, nothing on veach-mis).
+__device__ __attribute__((noinline)) LiSample light_sample_at(const float4* rec, V3 sp, V3 sn, V2 u) {
+    LightRec l;
+#pragma unroll
+    for (int k = 0; k < kLightRecVec4; ++k) l.l[k] = rec[k];
+    return light_sample(l, sp, sn, u);
 }
 
 // AreaLight::pdfLi (src/light.cpp:46-50)
