@@ -20,9 +20,13 @@ for a, b in pairs:
 def row(path, section, kern):
     s = open(path).read()
     s = s[s.index("== " + section):]
+    rows = []
     for l in s.split("\n"):
-        if l.startswith(kern):
-            return [float(x) for x in l.split()[1:]]
+        if l.startswith("== ") and rows:
+            break                       # the next section
+        if l.startswith(kern + " "):
+            rows.append([float(x) for x in l.split()[1:]])
+    return max(rows, key=lambda r: r[0]) if rows else None   # several instantiations: the one that ran longest
 
 
 def calls(path, kern):
@@ -45,6 +49,13 @@ for key, name, note in (("library-synth/fast", "library512spp", "gathers of 64-B
         sym = kern if kern == "k_shade" else kern + "_wave"
         v, n = row(path, "pmc3", sym), calls(path, sym)
         p1, p2 = row(path, "pmc1", sym), row(path, "pmc2", sym)
+        # cycles of the launches: GRBM_GUI_ACTIVE over the 8 XCDs, scaled from its pass to this one; when that pass was
+        # disturbed (the counter then runs far ahead of the kernel's own busy cycles) SQ_BUSY_CYCLES over the 32 shader
+        # engines of the same pass as the instruction count
+        cyc, cyc_sq = v[1] / 8 * p1[0] / v[0], p1[1] / 32
+        cycles_from = "GRBM_GUI_ACTIVE / 8"
+        if cyc > 1.3 * cyc_sq:
+            cyc, cycles_from = cyc_sq, "SQ_BUSY_CYCLES / 32"
         t[key][kern] = {
             "bytes_per_launch": int((v[2] + v[3]) * 64 / n),
             "how": "(TCC_EA0_RDREQ_sum + TCC_EA0_WRREQ_sum) x 64 B over the %d %s launches of one 512-spp pass (the size of the bench's passes); %s"
@@ -52,9 +63,10 @@ for key, name, note in (("library-synth/fast", "library512spp", "gathers of 64-B
             "source": rel,
             # SQ_INSTS_VALU over the VALU issue slots of the launches: a CDNA4 SIMD is 32 lanes wide and issues one wave64
             # instruction per 2 cycles when several waves are ready (one wave alone sustains one per 4 cycles: the second
-            # figure, reported next to it); 1024 SIMDs; cycles of the launches = GRBM_GUI_ACTIVE over the 8 XCDs
-            "valu_issue_frac": round(p1[4] * 2 / 1024 / (v[1] / 8 * p1[0] / v[0]), 3),
-            "valu_issue_frac_at_one_wave_rate": round(p1[4] * 4 / 1024 / (v[1] / 8 * p1[0] / v[0]), 3),
+            # figure, reported next to it); 1024 SIMDs
+            "valu_issue_frac": round(p1[4] * 2 / 1024 / cyc, 3),
+            "valu_issue_frac_at_one_wave_rate": round(p1[4] * 4 / 1024 / cyc, 3),
+            "cycles_from": cycles_from,
             "lanes_per_valu_inst_frac": round(p2[6] / (p2[2] * 64), 3),
             # share of the resident waves' time spent waiting (memory, LDS, dependencies): SQ_WAIT_ANY / SQ_WAVE_CYCLES
             "wave_wait_frac": round(p2[7] / p1[8] * (p1[0] / p2[0]), 3),
