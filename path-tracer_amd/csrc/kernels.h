@@ -7,7 +7,8 @@
 // src/integrator.cpp:58-73).
 //
 // Queues are SHARDED: the slot range is cut into shards of kShard slots, and every shard is an independent compacting
-// queue with its own counters.  A path never leaves its shard; a kernel is launched as grid (blocks, shards) and
+// queue with its own counters.  From bounce to bounce a path stays in its shard (it moves only when the thinned-out paths of
+// a pass are gathered into fewer shards, k_compact); a kernel is launched as grid (blocks, shards) and
 // block (x, s) works on entries [x * blockDim, ...) of shard s.  One device-wide counter would serialise every wave
 // of a launch on a single address (measured: ~90 returning atomics per microsecond per address, which made queue
 // allocation the bottleneck of the first version); with a few thousand shards each counter sees at most

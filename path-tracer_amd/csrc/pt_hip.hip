@@ -878,8 +878,9 @@ constexpr uint32_t kMaxIterations = 1u << 20;  // of the bounce loop, per pass
 // the queue counters into a pinned snapshot and launches shadow(b) and extend(b) without looking at it; the snapshot is
 // read before bounce b+1 is launched, by which time it has long arrived (shadow and extend are the long kernels).  That
 // is enough because every kernel walks its shard's queue with a block-stride loop bounded by the device-side counter, so
-// grids do not depend on the fills, and a shard's fill can only shrink from bounce to bounce (a path never leaves its
-// shard and produces at most one continuation and one shadow ray), so the fills of bounce b bound those of b+1.
+// grids do not depend on the fills, and a shard's fill can only shrink from bounce to bounce (a path stays in its shard
+// and produces at most one continuation and one shadow ray), so the fills of bounce b bound those of b+1 -- until the
+// paths are gathered into fewer, full shards (below), which starts the bound afresh.
 // Measured: letting the host run further ahead gains nothing (the gaps were never the syncs), and grids sized by stale
 // fills cost a lot -- a workgroup that finds nothing to do still takes ~0.2 us of dispatch (scratch + 12 KB LDS).
 int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bool count) {
