@@ -177,9 +177,9 @@ typedef struct pt_stats {
     double   kernel_ms[PT_MAX_KERNEL_STATS];
     uint64_t kernel_launches[PT_MAX_KERNEL_STATS];
 } pt_stats;
-/* indices into kernel_ms / kernel_launches; PT_K_FINISH = the one launch that runs the last few paths of a pass (chains of
- * specular bounces beyond max_bounce iterations) to their end; PT_K_COMPACT = the gathering of the surviving
- * paths into a few dense shards */
+/* indices into kernel_ms / kernel_launches; PT_K_FINISH = the launches that run few paths for many iterations in one go
+ * (the thinned-out tail of a pass; the last chains of specular bounces beyond max_bounce iterations);
+ * PT_K_COMPACT = the gathering of the surviving paths into a few dense shards */
 enum { PT_K_GENERATE = 0, PT_K_EXTEND = 1, PT_K_SHADE = 2, PT_K_SHADOW = 3, PT_K_FILM = 4, PT_K_RETRACE = 5, PT_K_FINISH = 6, PT_K_COMPACT = 7 };
 
 typedef struct pt_hip_scene pt_hip_scene;
