@@ -137,12 +137,12 @@ constexpr int kMiscWords = 24;
 
 // A ray that a wave-refill kernel handed back, in reference order: the whole query (plain-division rays, kDeferExact), or
 // bounded by `bound` when the ordered pass has already established that the nearest accepted triangle lies before it.
-template <class C>
+template <int ROWS = kLdsDepth, class C>
 PTD bool trace_deferred(const DevScene& sc, const RayD& ray, float bound, HitD& hit, uint32_t* lds, uint32_t* retrace_counter, C& wc) {
     const RayPre pre = make_pre(sc, ray);
-    if (bound == kDeferExact || pre.special) return closest_exact(sc, ray, hit, lds, wc);
+    if (bound == kDeferExact || pre.special) return closest_exact<C, ROWS>(sc, ray, hit, lds, wc);
     if (retrace_counter) atomicAdd(retrace_counter, 1u);
-    return closest_exact_t<false>(sc, ray, pre, bound, hit, lds, wc);
+    return closest_exact_t<false, C, ROWS>(sc, ray, pre, bound, hit, lds, wc);
 }
 
 // add a wave's work counters to the global 64-bit totals (counting builds only)
@@ -365,7 +365,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE_GEN,
     __shared__ uint32_t s_stack[wave_lds_words<Lane>()];
     const uint32_t shard = shard_index();
     C wc;
-    closest_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
+    __shared__ uint4 s_nodes[treelet_lds_vec4<Lane>()];
+    const Treelet tl = wave_treelet<Lane>(sc, s_nodes);
+    closest_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, tl, wc);
     if (last_block_of_shard(done, shard)) {
         const size_t sbase = size_t(shard) * kShard;
         const uint32_t n = load_fresh(io.dq.count + shard);
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE_GEN,
                 j = load_fresh(&io.dq.e[sbase + k].x);
                 const float bound = as_f(load_fresh(&io.dq.e[sbase + k].y));
                 io.load(sc, shard, j, ray, c);
-                trace_deferred(sc, ray, bound, h, s_stack + threadIdx.x, misc, wc);
+                trace_deferred<Lane::kLdsRows>(sc, ray, bound, h, s_stack + threadIdx.x, misc, wc);
             }
             io.emit(sc, shard, k < n, j, h, c, ray.o, ray.d);
         }
@@ -430,7 +432,7 @@ struct ExtendIo {
 };
 
 // The deferred rays of one shard, by one workgroup, in reference order (order-sensitive ones only up to their bound).
-template <class C>
+template <int ROWS, class C>
 PTD void extend_deferred(const DevScene& sc, const PathQ& q, const HitQ& hq, const DeferQ& dq, uint32_t shard, uint32_t* lds_stack,
                          uint32_t* misc, C& wc) {
     const size_t sbase = size_t(shard) * kShard;
@@ -447,7 +449,7 @@ PTD void extend_deferred(const DevScene& sc, const PathQ& q, const HitQ& hq, con
             const float4 a = q.a[sbase + j], b = q.b[sbase + j];
             c = q.c[sbase + j];
             const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, __builtin_huge_valf()};
-            found = trace_deferred(sc, ray, bound, h, lds_stack, misc, wc);
+            found = trace_deferred<ROWS>(sc, ray, bound, h, lds_stack, misc, wc);
         }
         const uint32_t local = wave_alloc(found, hq.count + shard);
         if (found) {
@@ -466,8 +468,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE
     const uint32_t shard = shard_index();
     zero_counters(zl, shard);
     C wc;
-    closest_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
-    if (last_block_of_shard(done, shard)) extend_deferred(sc, io.q, io.hq, io.dq, shard, s_stack + threadIdx.x, misc, wc);
+    __shared__ uint4 s_nodes[treelet_lds_vec4<Lane>()];
+    const Treelet tl = wave_treelet<Lane>(sc, s_nodes);
+    closest_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, tl, wc);
+    if (last_block_of_shard(done, shard)) extend_deferred<Lane::kLdsRows>(sc, io.q, io.hq, io.dq, shard, s_stack + threadIdx.x, misc, wc);
     flush_counts(wc, misc, 1);
 }
 
@@ -512,7 +516,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE_SHAD
     __shared__ uint32_t s_stack[wave_lds_words<Lane>()];
     const uint32_t shard = shard_index();
     C wc;
-    any_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, wc);
+    __shared__ uint4 s_nodes[treelet_lds_vec4<Lane>()];
+    const Treelet tl = wave_treelet<Lane>(sc, s_nodes);
+    any_wave<Lane>(sc, io, shard, fetch, s_stack + threadIdx.x, tl, wc);
     if (last_block_of_shard(done, shard)) {  // plain-division rays of the shard
         const size_t sbase = size_t(shard) * kShard;
         const uint32_t n = load_fresh(io.dq.count + shard);
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WPE_SHAD
             const float4 a = io.sh.a[sbase + j], b = io.sh.b[sbase + j];
             const RayD ray{V3{a.x, a.y, a.z}, V3{a.w, b.x, b.y}, 0.0f, b.z};
             int32_t first_prim;
-            if (!any_exact(sc, ray, first_prim, s_stack + threadIdx.x, wc)) {
+            if (!any_exact<C, Lane::kLdsRows>(sc, ray, first_prim, s_stack + threadIdx.x, wc)) {
                 const float4 v = io.sh.c[sbase + j];
                 const uint32_t slot = as_u(b.w);
                 float4 L = io.lbuf[slot];
@@ -563,7 +569,9 @@ template <class C>
 __global__ __launch_bounds__(kBlock) void k_intersect_wave(DevScene sc, BatchClosestIo io, uint32_t* fetch, uint32_t* misc) {
     __shared__ uint32_t s_stack[wave_lds_words<ClosestLane>()];
     C wc;
-    closest_wave<ClosestLane>(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
+    __shared__ uint4 s_nodes[treelet_lds_vec4<ClosestLane>()];
+    const Treelet tl = wave_treelet<ClosestLane>(sc, s_nodes);
+    closest_wave<ClosestLane>(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, tl, wc);
     flush_counts(wc, misc, 1);
 }
 
@@ -606,7 +614,9 @@ template <class C>
 __global__ __launch_bounds__(kBlock) void k_occluded_wave(DevScene sc, BatchAnyIo io, uint32_t* fetch, uint32_t* misc) {
     __shared__ uint32_t s_stack[wave_lds_words<AnyLane>()];
     C wc;
-    any_wave<AnyLane>(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, wc);
+    __shared__ uint4 s_nodes[treelet_lds_vec4<AnyLane>()];
+    const Treelet tl = wave_treelet<AnyLane>(sc, s_nodes);
+    any_wave<AnyLane>(sc, io, blockIdx.y, fetch, s_stack + threadIdx.x, tl, wc);
     flush_counts(wc, misc, 2);
 }
 

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <queue>
 #include <string>
 #include <thread>
 #include <vector>
@@ -543,6 +544,31 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
                 }
             }
         }
+        // The navigation nodes a ray is most likely to visit come first: starting at the root, the node with the largest
+        // surface among the children of those already taken (a ray that meets a box meets a box inside it with a
+        // probability of about the ratio of their surfaces), kTreeletMax of them.  The traversal kernels keep a prefix of
+        // this list in LDS (treelet_fill in traverse.h); the other nodes keep their order behind it.
+        if (!order.empty()) {
+            std::priority_queue<std::pair<double, uint32_t>> frontier;
+            frontier.push({surface(order[0]), order[0]});
+            std::vector<uint32_t> top;
+            std::vector<uint8_t> in_top(d->n_nodes, 0);
+            while (!frontier.empty() && top.size() < kTreeletMax) {
+                const uint32_t n = frontier.top().second;
+                frontier.pop();
+                top.push_back(n);
+                in_top[n] = 1;
+                uint32_t slots[kWide];
+                const int ns = collapse(n, slots);
+                for (int k = 0; k < ns; ++k)
+                    if (!leaf_like(slots[k])) frontier.push({surface(slots[k]), slots[k]});
+            }
+            for (uint32_t n : order)
+                if (!in_top[n]) top.push_back(n);
+            order.swap(top);
+            for (size_t i = 0; i < order.size(); ++i) wide_id[order[i]] = uint32_t(i);
+        }
+        dev.n_treelet = uint32_t(std::min<size_t>(kTreeletMax, order.size()));
         auto ref_of = [&](uint32_t ni) -> uint32_t {
             const pt_bvh_node& b = d->nodes[ni];
             if (b.count) return kLeafBit | (b.count << kLeafCountShift) | slot_of[ni];
@@ -1869,6 +1895,19 @@ extern "C" int pt_hip_debug_phase(unsigned long long* out, int reset) {
     if (reset) {
         static const unsigned long long zero[4][8] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_phase), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+#ifdef PT_NODE_HIST
+// diagnostic builds only: reads, and optionally clears, the per-node visit counters
+extern "C" int pt_hip_debug_node_hist(uint32_t* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_node_hist), sizeof(uint32_t) * ptd::kNodeHist) != hipSuccess) return -1;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(ptd::g_node_hist)) != hipSuccess) return -1;
+        if (hipMemset(p, 0, sizeof(uint32_t) * ptd::kNodeHist) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -23,6 +23,10 @@ constexpr uint32_t kLeafFirstMask = (1u << kLeafCountShift) - 1u;
 constexpr uint32_t kFatLeafTris = PT_FAT_LEAF_TRIS;
 static_assert(kFatLeafTris <= 15u, "the leaf reference has four bits for the triangle count");
 
+// The first navigation nodes are the ones rays visit most (the root, then by surface); the traversal kernels serve a
+// prefix of them from LDS.  kTreeletMax bounds what the scene builder orders that way.
+constexpr uint32_t kTreeletMax = 1024;
+
 // Shading record of one triangle: exactly one 128-byte line, 8 x float4, everything the shade step needs about the
 // surface it hit (the reference chases Triangle* -> TriangleMesh -> index arrays -> vertex arrays, and Material*,
 // AreaLight*: include/pt/shape.h:58-63, include/pt/mesh.h:31-55):
@@ -61,6 +65,7 @@ struct DevScene {
     const uint4* qnodes;
     float q_org[3], q_step[3];
     uint32_t wide_root;  // reference of the root (an interior index, or a leaf reference for tiny scenes)
+    uint32_t n_treelet;  // navigation nodes [0, n_treelet) are listed most-visited first (at most kTreeletMax)
     // ---- leaf array, 3 x float4 per slot: per leaf one header slot {P.lo.xyz, P.hi.x} {P.hi.yz, bits(flags), 0} {0}
     //      (P = the leaf's parent node) followed by its triangles {p0.xyz, bits(prim)} {e1.xyz, 0} {e2.xyz, 0};
     //      a binary leaf node's `first` is the slot of its first triangle

@@ -109,12 +109,14 @@ struct DistStackN {
     PTD bool empty() const { return sp == 0; }
 };
 
-// LDS rows of the ordered traversals' stacks (closest hit: references and entry distances, kDistRows each)
+// LDS rows of the ordered traversals' stacks (closest hit: references and entry distances, kDistRows each): 16 rows = 8 KB
+// per workgroup, which with the 2 KB of the LDS treelet (below) lets 14 workgroups -- 7 waves per SIMD, what the shadow
+// kernel is built for -- share a CU's 160 KB (20 rows measured the same on their own).
 #ifndef PT_DIST_ROWS
-#define PT_DIST_ROWS 10
+#define PT_DIST_ROWS 8
 #endif
 #ifndef PT_ANY_ROWS
-#define PT_ANY_ROWS 20
+#define PT_ANY_ROWS 16
 #endif
 constexpr int kDistRows = PT_DIST_ROWS;
 constexpr int kAnyRows = PT_ANY_ROWS;
@@ -344,6 +346,60 @@ PTD bool cheap_go(const BoxC& b, float tmin, float far) {
 constexpr uint32_t kEmptyRef = 0xffffffffu;  // unused slot of a navigation node
 constexpr int kWide = 4;                      // slots per navigation node
 
+// The top of the navigation tree in LDS.  A CU serves per-lane 16-byte loads of different addresses at about one lane
+// per clock, whatever cache level they hit in (measured: tools/gather_roof.hip; 64 lanes x 4 loads per node), and that
+// rate is what the ordered traversal kernels run at.  LDS reads go through another path at the same time, so every node
+// visit served from LDS is taken off the binding resource: each workgroup copies navigation nodes [0, kTreelet) -- the
+// scene builder lists the most visited nodes first -- into LDS when it starts, and a lane whose current node is one of
+// them reads it with four ds_read_b128.  Results do not depend on where a node's words come from.
+#ifndef PT_TREELET
+#define PT_TREELET 32
+#endif
+constexpr uint32_t kTreelet = PT_TREELET;
+static_assert(kTreelet <= kTreeletMax, "the scene builder orders only the first kTreeletMax navigation nodes by visit probability");
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u4;
+
+struct Treelet {
+    const lds_u4* nodes;  // LDS copies of navigation nodes [0, n)
+    uint32_t n;
+};
+
+// By all threads of a workgroup, before any of them traverses.  s_nodes: kTreelet * kWide uint4 of LDS.
+PTD Treelet treelet_fill(const DevScene& sc, uint4* s_nodes) {
+    const uint32_t n = min(kTreelet, sc.n_treelet);
+    for (uint32_t i = threadIdx.x; i < n * kWide; i += blockDim.x) s_nodes[i] = sc.qnodes[i];
+    __syncthreads();
+    return Treelet{(const lds_u4*)reinterpret_cast<u32x4*>(s_nodes), n};
+}
+
+// Diagnostic builds (-DPT_NODE_HIST): visits per navigation node (the last counter takes all nodes beyond the array).
+#ifdef PT_NODE_HIST
+constexpr uint32_t kNodeHist = 1u << 20;
+__device__ uint32_t g_node_hist[kNodeHist];
+#endif
+
+// the four slots of navigation node `cur`
+PTD void nav_fetch(const DevScene& sc, const Treelet& tl, uint32_t cur, uint4& c0, uint4& c1, uint4& c2, uint4& c3) {
+#ifdef PT_NODE_HIST
+    atomicAdd(&g_node_hist[min(cur, kNodeHist - 1u)], 1u);
+#endif
+    if (cur < tl.n) {
+        const lds_u4* w = tl.nodes + kWide * cur;
+        const u32x4 a = w[0], b = w[1], c = w[2], d = w[3];
+        c0 = make_uint4(a.x, a.y, a.z, a.w);
+        c1 = make_uint4(b.x, b.y, b.z, b.w);
+        c2 = make_uint4(c.x, c.y, c.z, c.w);
+        c3 = make_uint4(d.x, d.y, d.z, d.w);
+    } else {
+        const uint4* w = sc.qnodes + kWide * size_t(cur);
+        c0 = w[0];
+        c1 = w[1];
+        c2 = w[2];
+        c3 = w[3];
+    }
+}
+
 // Header record of a leaf in the triangle array: {P.lo.xyz, P.hi.x} {P.hi.yz, bits(flags), 0} {unused}, P = the leaf's
 // parent node.  kLeafUntested: the leaf is the root (the reference tests no box at all).
 constexpr uint32_t kLeafUntested = 1u;
@@ -394,10 +450,11 @@ struct TriRecord {
 // or before it: candidates and subtrees beyond the bound cannot influence which of the nearer candidates the reference
 // ends up with (they never make it skip a box that contains a nearer candidate), so leaving them out reproduces the
 // reference's result at a fraction of the work.  With bound = +inf this is the plain reference traversal.
-template <bool SPECIAL, class C>
+// ROWS: rows of the [row][lane] LDS array at lds_stack that this walk may use (the rest of its stack is private memory).
+template <bool SPECIAL, class C, int ROWS = kLdsDepth>
 PTD bool closest_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre, float bound, HitD& hit, uint32_t* lds_stack, C& wc) {
-    uint32_t spill[kSpillDepth];
-    Stack st;
+    uint32_t spill[kMaxStack - ROWS];
+    StackN<ROWS> st;
     st.init(lds_stack, spill);
     st.push(0u);
     float max_dis = fminf(ray.tmax, bound);
@@ -439,17 +496,17 @@ PTD bool closest_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre,
 }
 
 // Closest hit in the reference's visit order.  Returns true when something was hit.
-template <class C>
+template <class C, int ROWS = kLdsDepth>
 PTD bool closest_exact(const DevScene& sc, const RayD& ray, HitD& hit, uint32_t* lds_stack, C& wc) {
     const RayPre pre = make_pre(sc, ray);
-    if (pre.special) return closest_exact_t<true>(sc, ray, pre, __builtin_huge_valf(), hit, lds_stack, wc);
-    return closest_exact_t<false>(sc, ray, pre, __builtin_huge_valf(), hit, lds_stack, wc);
+    if (pre.special) return closest_exact_t<true, C, ROWS>(sc, ray, pre, __builtin_huge_valf(), hit, lds_stack, wc);
+    return closest_exact_t<false, C, ROWS>(sc, ray, pre, __builtin_huge_valf(), hit, lds_stack, wc);
 }
 
-template <bool SPECIAL, class C>
+template <bool SPECIAL, class C, int ROWS = kLdsDepth>
 PTD bool any_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre, int32_t& first_prim, uint32_t* lds_stack, C& wc) {
-    uint32_t spill[kSpillDepth];
-    Stack st;
+    uint32_t spill[kMaxStack - ROWS];
+    StackN<ROWS> st;
     st.init(lds_stack, spill);
     st.push(0u);
     first_prim = -1;
@@ -483,11 +540,11 @@ PTD bool any_exact_t(const DevScene& sc, const RayD& ray, const RayPre& pre, int
 }
 
 // Any hit in the reference's visit order; first_prim receives the first accepted triangle or -1.
-template <class C>
+template <class C, int ROWS = kLdsDepth>
 PTD bool any_exact(const DevScene& sc, const RayD& ray, int32_t& first_prim, uint32_t* lds_stack, C& wc) {
     const RayPre pre = make_pre(sc, ray);
-    if (pre.special) return any_exact_t<true>(sc, ray, pre, first_prim, lds_stack, wc);
-    return any_exact_t<false>(sc, ray, pre, first_prim, lds_stack, wc);
+    if (pre.special) return any_exact_t<true, C, ROWS>(sc, ray, pre, first_prim, lds_stack, wc);
+    return any_exact_t<false, C, ROWS>(sc, ray, pre, first_prim, lds_stack, wc);
 }
 
 // ------------------------------------------------------------------------------------------------ self test

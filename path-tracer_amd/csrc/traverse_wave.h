@@ -93,13 +93,15 @@ struct PhaseStats {
 //   begin(sc, ray, pre)            start a query
 //   box_ready() / leaf_ready()     the next step is a box step / a triangle step
 //   finished()                     the query has ended
-//   inner(sc, st, wc), leaf(sc, st, wc)
+//   kTreeletNodes                  navigation nodes the lane type wants in LDS (0: none)
+//   inner(sc, tl, st, wc), leaf(sc, st, wc)
 //   settle(sc, [bound,] wc)        once per query when the walk has ended: true = repeat it in reference order
 struct ClosestLane {
     typedef DistStack StackT;
     static constexpr int kSpillWords = 2 * DistStack::kSpill;
     static constexpr int kLdsRows = 2 * DistStack::kRows;
     static constexpr bool kReferenceOrder = false;
+    static constexpr uint32_t kTreeletNodes = kTreelet;
     PTD void idle() {
         cur = kDone;
         hit = HitD{-1, 0.0f, 0.0f, 0.0f};
@@ -153,10 +155,10 @@ struct ClosestLane {
     // one navigation node: its (up to) four slots through the conservative test; the nearest one that can hold a candidate
     // is visited next, the others are deferred in far-to-near order, each with its entry distance
     template <class C>
-    PTD void inner(const DevScene& sc, DistStack& st, C& wc) {
-        const uint4* w = sc.qnodes + kWide * size_t(cur);
+    PTD void inner(const DevScene& sc, const Treelet& tl, DistStack& st, C& wc) {
         wc.node();
-        const uint4 c0 = w[0], c1 = w[1], c2 = w[2], c3 = w[3];
+        uint4 c0, c1, c2, c3;
+        nav_fetch(sc, tl, cur, c0, c1, c2, c3);
         const float inf = __builtin_huge_valf(), far = cull_bound();
         const BoxC b0 = box_cheap(c0.x, c0.y, c0.z, cr), b1 = box_cheap(c1.x, c1.y, c1.z, cr);
         const BoxC b2 = box_cheap(c2.x, c2.y, c2.z, cr), b3 = box_cheap(c3.x, c3.y, c3.z, cr);
@@ -255,6 +257,7 @@ struct AnyLane {
     static constexpr int kSpillWords = AnyStack::kSpill;
     static constexpr int kLdsRows = AnyStack::kRows;
     static constexpr bool kReferenceOrder = false;
+    static constexpr uint32_t kTreeletNodes = kTreelet;
     PTD void idle() {
         cur = kDone;
         occluded = false;
@@ -287,10 +290,10 @@ struct AnyLane {
     // reaches a leaf iff it accepts the leaf's parent box.  Any walk that visits every such leaf that can hold an accepted
     // triangle, and tries a leaf's triangles only after the parent's exact test, returns what the reference returns.
     template <class C>
-    PTD void inner(const DevScene& sc, AnyStack& st, C& wc) {
-        const uint4* w = sc.qnodes + kWide * size_t(cur);
+    PTD void inner(const DevScene& sc, const Treelet& tl, AnyStack& st, C& wc) {
         wc.node();
-        const uint4 c0 = w[0], c1 = w[1], c2 = w[2], c3 = w[3];
+        uint4 c0, c1, c2, c3;
+        nav_fetch(sc, tl, cur, c0, c1, c2, c3);
         const bool g0 = bool(c0.w != kEmptyRef) & cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), tmin, far_end);
         const bool g1 = bool(c1.w != kEmptyRef) & cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), tmin, far_end);
         const bool g2 = bool(c2.w != kEmptyRef) & cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), tmin, far_end);
@@ -368,6 +371,7 @@ struct ExactClosestLane {
     static constexpr int kSpillWords = kSpillDepth;
     static constexpr int kLdsRows = kLdsDepth;
     static constexpr bool kReferenceOrder = true;
+    static constexpr uint32_t kTreeletNodes = 0;  // walks the binary nodes
     RayPre pre;
     PTD const V3& org() const { return pre.o; }
     PTD const V3& dir() const { return pre.d; }
@@ -394,7 +398,7 @@ struct ExactClosestLane {
     PTD void next(Stack& st) { cur = st.empty() ? kNoNode : st.pop(); }
 
     template <class C>
-    PTD void inner(const DevScene& sc, Stack& st, C& wc) {
+    PTD void inner(const DevScene& sc, const Treelet&, Stack& st, C& wc) {
         wc.node();
         const float4 n0 = sc.nodes[2 * size_t(cur)];
         const float4 n1 = sc.nodes[2 * size_t(cur) + 1];
@@ -437,6 +441,7 @@ struct ExactAnyLane {
     static constexpr int kSpillWords = kSpillDepth;
     static constexpr int kLdsRows = kLdsDepth;
     static constexpr bool kReferenceOrder = true;
+    static constexpr uint32_t kTreeletNodes = 0;  // walks the binary nodes
     RayPre pre;
     float tmax;
     bool occluded;
@@ -460,7 +465,7 @@ struct ExactAnyLane {
     PTD void next(Stack& st) { cur = st.empty() ? kNoNode : st.pop(); }
 
     template <class C>
-    PTD void inner(const DevScene& sc, Stack& st, C& wc) {
+    PTD void inner(const DevScene& sc, const Treelet&, Stack& st, C& wc) {
         wc.node();
         const float4 n0 = sc.nodes[2 * size_t(cur)];
         const float4 n1 = sc.nodes[2 * size_t(cur) + 1];
@@ -529,7 +534,7 @@ PTD uint32_t wave_fetch(bool want, uint32_t* counter, uint32_t count, bool& more
 // lanes that have a result (run per loop round for the one or two lanes that just ended, settle() -- an exact box
 // decision behind a dependent fetch -- cost as much as a box step of the whole wave).
 template <class Lane, class Io, class C>
-PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, C& wc) {
+PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, const Treelet& tl, C& wc) {
     const uint32_t count = io.count(shard);
     uint32_t spill[Lane::kSpillWords];
     typename Lane::StackT st;
@@ -587,7 +592,7 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
                 const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
                 if (n_inner == 0u) break;
                 ps.box(n_inner);
-                if (inner) L.inner(sc, st, wc);
+                if (inner) L.inner(sc, tl, st, wc);
                 if (n_inner < kMinBoxLanes) break;
             }
             if constexpr (!Lane::kReferenceOrder) ps.leaf(state == kLaneBusy && L.leaf_ready(), L.cur);
@@ -601,7 +606,7 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
 // Any hit for the rays of one shard.  Io: count(shard), load(sc, shard, j, RayD&, Carry&),
 // commit(sc, shard, fin, j, occluded, defer, carry) -- per lane, no wave-level operation required.
 template <class Lane, class Io, class C>
-PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, C& wc) {
+PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, uint32_t* lds_stack, const Treelet& tl, C& wc) {
     const uint32_t count = io.count(shard);
     uint32_t spill[Lane::kSpillWords];
     typename Lane::StackT st;
@@ -653,7 +658,7 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
                 const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
                 if (n_inner == 0u) break;
                 ps.box(n_inner);
-                if (inner) L.inner(sc, st, wc);
+                if (inner) L.inner(sc, tl, st, wc);
                 if (n_inner < kMinBoxLanes) break;
             }
             if constexpr (!Lane::kReferenceOrder) ps.leaf(state == kLaneBusy && L.leaf_ready(), L.cur);
@@ -666,9 +671,25 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
 
 // LDS words per workgroup of a kernel built on the wave loops for lane type Lane; the follow-up traversals of deferred
 // rays use the same memory as a plain stack of kLdsDepth rows
+// uint4 of LDS for the workgroup's copy of the top navigation nodes, for lane type Lane (at least one, so that the array
+// can be declared)
+template <class Lane>
+constexpr int treelet_lds_vec4() {
+    return Lane::kTreeletNodes != 0u ? int(Lane::kTreeletNodes) * kWide : 1;
+}
+template <class Lane>
+PTD Treelet wave_treelet(const DevScene& sc, uint4* s_nodes) {
+    if constexpr (Lane::kTreeletNodes != 0u)
+        return treelet_fill(sc, s_nodes);
+    else
+        return Treelet{nullptr, 0u};
+}
+
+// LDS words per workgroup of a kernel built on the wave loops for lane type Lane; the follow-up traversals of deferred
+// rays use the same memory as a plain stack of Lane::kLdsRows rows
 template <class Lane>
 constexpr int wave_lds_words() {
-    return (Lane::kLdsRows > kLdsDepth ? Lane::kLdsRows : kLdsDepth) * kBlock;
+    return Lane::kLdsRows * kBlock;
 }
 
 }  // namespace ptd
