@@ -14,6 +14,8 @@ import glob
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +25,22 @@ sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "python"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+# What binds the traversal kernels is the rate at which a CU serves per-lane loads of DIFFERENT addresses: about one lane
+# and 16 bytes per clock, whichever cache level answers (tools/gather_roof.hip: dependent chains of 64-byte records at 6
+# waves per SIMD; profiles/r3_gather_roof.jsonl).  The fallback is that file's figure for an L2-resident table.
+GATHER_PEAK_FALLBACK = 2.27e9   # 16-byte lane loads per second and CU
+N_CUS = 256
+# 16-byte (or narrower) per-lane loads and stores of each kernel per unit besides the BVH records: a navigation node is
+# 4 loads when it comes from memory (a binary node 2), a triangle record 3 (layouts: path-tracer_amd/csrc/kernels.h)
+LANE_ACCESSES = {
+    "generate": 3 + 7,            # three Sobol' table words; radiance slot, path state (4) and hit entry (2) written
+    "extend": 3 + 2,              # ray read (a, b, c); hit entry written
+    "shadow": 2 + 0.5 * 3,        # ray read; contribution read and radiance slot read and written when unoccluded (~half)
+    "shade": 2 + 4 + 8 + 6 + 6 + 7,  # hit entry, path state, triangle record, Sobol' window, light record in; shadow entry + next state out
+    "film": 1 + 3,
+}
+NODE_LOADS = {"exact": 2, "fast": 4}
+TRI_LOADS = 3
 NODE_BYTES = {"exact": 32, "fast": 64}   # node record read per visit: binary node / 4-wide navigation node
 TRI_BYTES = 48             # leaf-array record: triangle {p0, e1, e2, prim} or leaf header (parent box)
 # streamed bytes per unit of each kernel besides the BVH records (layouts: path-tracer_amd/csrc/kernels.h)
@@ -88,18 +106,42 @@ def shared_tree(sd, rank, world, barrier, device=0):
     return tree
 
 
+def gather_peak():
+    """Measured roof of a CU's dependent-gather rate (16-byte lane loads per second): the 64-byte-record chain on a 1 MB
+    table at six waves per SIMD from the committed run of tools/gather_roof.hip."""
+    try:
+        for line in open(os.path.join(ROOT, "profiles", "r3_gather_roof.jsonl")):
+            d = json.loads(line)
+            if d["mode"] == "g4" and d["table_bytes"] == 1 << 20 and d["waves_per_simd"] == 6 and d.get("valu_per_step", 0) == 0:
+                return d["lane_records_per_cu_per_us"] * 1e6 * 4, "profiles/r3_gather_roof.jsonl"
+    except (OSError, ValueError, KeyError):
+        pass
+    return GATHER_PEAK_FALLBACK, "fallback constant"
+
+
+def host_cores():
+    """(threads the CPU baseline uses, cores this process may run on, cores of the machine).  The GPU box gives a one-GPU
+    job a share of a much larger host, and says so through OMP_NUM_THREADS."""
+    machine = os.cpu_count() or 1
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else machine
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return max(1, min(allowed, share) if share > 0 else allowed), allowed, machine
+
+
 def cpu_baseline(sd, budget_s=15.0):
     """The oracle (a port of the reference algorithm) on the host cores, on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
-    cores = min(os.cpu_count() or 1, 16)
+    cores, allowed, machine = host_cores()
     o = orc.Scene(sd)
     _, st = o.render(0, 1, nthreads=cores)              # probe: 1 spp, whole frame
     rate = st["paths"] / max(st["seconds"], 1e-6)
     spp = int(max(1, min(64, budget_s * rate / st["paths"])))
     _, st = o.render(0, spp, nthreads=cores)
     rays = st["closest_rays"] + st["any_rays"]
-    return {"value": rays / st["seconds"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": rays / st["seconds"] / 1e6, "unit": "Mrays/s", "cores": cores, "cores_allowed": allowed, "cores_of_machine": machine,
+            "cores_note": "threads used = this job's share of the host (OMP_NUM_THREADS on the GPU box), never more than its affinity mask",
+            "kind": "port",
             "sample": "whole frame, %d spp of the same workload (%.1f s)" % (spp, st["seconds"]),
             "samples_per_s": st["paths"] / st["seconds"],
             "ref_order_nodes_per_ray": st["nodes_visited"] / rays, "ref_order_tris_per_ray": st["tris_tested"] / rays}
@@ -120,6 +162,16 @@ def main():
                          "tile = the ranks share the 32x32 pixel blocks of one frame of --spp samples (always strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Launched bare: start one rank per GPU as fresh child processes.  Nothing in this process has touched a GPU yet
+        # (a process that has must not be replaced or forked into ranks), and it only waits for them.
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -194,23 +246,32 @@ def main():
         extra_ms = {k: sum(s["kernel_ms"].get(k, 0.0) for s in stats) for k in ("finish", "compact")}   # tail launch, path gathering
         kn = {k: sum(s["kernel_launches"].get(k, 0) for s in stats) for k in api.KERNEL_NAMES[:5]}
         dominant = max(kms, key=kms.get)
-        # average BVH records per ray of each traversal kernel from an instrumented (untimed) pass over 8 spp
-        cst = scene.render_device(film.data_ptr(), 0, min(8, a.spp), traversal=mode, flags=api.FLAG_COUNT_WORK)
+        # average BVH records per ray of each traversal kernel from an instrumented (untimed) pass of the size of the timed
+        # region's passes (which kernels carry the late bounces depends on the pass size)
+        pass_spp = max(1, stats[0]["samples_per_pass"])
+        cst = scene.render_device(film.data_ptr(), s0, min(s1, s0 + pass_spp), traversal=mode, flags=api.FLAG_COUNT_WORK, block=share)
         units = {"generate": sum(s["paths"] for s in stats), "film": sum(s["paths"] for s in stats),
                  "extend": sum(s["closest_rays"] - s["paths"] for s in stats), "shadow": sum(s["any_rays"] for s in stats),
                  "shade": sum(s["closest_rays"] for s in stats)}   # upper bound: misses leave the queue before shading
         cunits = {"generate": cst["paths"], "extend": cst["closest_rays"] - cst["paths"], "shadow": cst["any_rays"]}
         per_unit = dict(UNIT_BYTES)
+        lane_acc = dict(LANE_ACCESSES)
         bvh = {}
         for k in ("generate", "extend", "shadow"):
             n_node = cst["nodes_fetched"][k] / max(cunits[k], 1)
+            n_lds = cst["nodes_from_lds"][k] / max(cunits[k], 1)
             n_tri = cst["tris_fetched"][k] / max(cunits[k], 1)
-            bvh[k] = {"nodes_per_ray": n_node, "tris_per_ray": n_tri}
+            bvh[k] = {"nodes_per_ray": n_node, "of_them_from_lds": n_lds, "tris_per_ray": n_tri}
             per_unit[k] += NODE_BYTES[a.traversal] * n_node + TRI_BYTES * n_tri
-        achieved = units[dominant] * per_unit[dominant] / (kms[dominant] * 1e-3) / 1e9 if kms[dominant] > 0 else 0.0
-        # Hardware counters cannot be read from inside this process: what binds the dominant kernel comes from the committed
-        # rocprofv3 --pmc passes of the same workload and pass size (profiles/traffic.json), stamped with the digest of the
-        # device sources they were measured on; a different digest marks them stale.
+            lane_acc[k] += NODE_LOADS[a.traversal] * (n_node - n_lds) + TRI_LOADS * n_tri
+        seconds = kms[dominant] * 1e-3
+        achieved_hbm = units[dominant] * per_unit[dominant] / seconds / 1e9 if seconds > 0 else 0.0
+        achieved_gather = units[dominant] * lane_acc[dominant] / seconds / 1e9 if seconds > 0 else 0.0   # G lane accesses per second
+        peak_cu, peak_src = gather_peak()
+        peak_gather = peak_cu * N_CUS / 1e9
+        # Hardware counters cannot be read from inside this process: the counter figures of the dominant kernel come from the
+        # committed rocprofv3 --pmc passes of the same workload and pass size (profiles/traffic.json), stamped with the digest
+        # of the device sources they were measured on; a different digest marks them stale.
         counters, stale = {}, None
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("%s/%s" % (a.workload, a.traversal), {}).get("k_" + dominant)
@@ -228,6 +289,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if "synth" in a.workload else "reference mesh, no textures",
             "config": {"workload": label, "integrator": "MIS path tracer, 32 bounces, Sobol'",
                        "spp_per_frame" if strong else "spp_per_gpu": a.spp, "traversal": a.traversal,
+                       "traversal_note": ("ordered 4-wide walk: identical to the reference-order walk in every bit on all tested rays (parity tests, fuzzers), "
+                                          "not by construction: a ray that grazes a large triangle below 1e-4 rad with |det| just above the reference's 1e-5 "
+                                          "threshold can differ; --traversal exact follows the reference there too")
+                                         if a.traversal == "fast" else "reference visit order: identical to the reference by construction",
+                       "samples_per_pass": pass_spp,
                        "parallelism": (("32x32-block split x%d" if tiles else ("spp-range split of one frame x%d" if strong else "spp-range x%d, one frame share each"))
                                        + " + 1 film reduce, tree built once per node") % world},
             "samples_per_s": paths_total / dt,
@@ -235,28 +301,34 @@ def main():
             "kernel_ms_per_step": dict({k: v / a.steps for k, v in kms.items()}, **{k: v / a.steps for k, v in extra_ms.items()}),
             "kernel_launches_per_step": {k: v / a.steps for k, v in kn.items()},
             "bvh_records_per_ray": bvh,
-            # The traversal kernels are not bound by HBM: the records they gather are served by L2 / Infinity Cache.  Nor do
-            # they fill the vector ALU: a CDNA4 SIMD can issue a wave64 instruction every 2 cycles, and the kernel uses under
-            # half of those slots, at half the lanes, because its waves spend most of their time waiting for the next
-            # dependent gather (`wave_wait_frac`) and six of them per SIMD do not cover that.  `frac` is the share of the
-            # vector ALU's lane throughput that does useful work (issue share x active lanes); the algorithmic-bytes figure
-            # the contract asks for is kept as `achieved` against the HBM peak, next to the bytes that really crossed the
-            # fabric.
-            "roofline": {"bound": "latency", "bound_note": "dependent gathers (one node per step and lane) at 6 waves per SIMD; neither the HBM nor the VALU roof is near",
+            # The dominant kernel against the resource that binds it.  The traversal kernels gather: every lane loads its own
+            # node and triangle records, 16 bytes per instruction, and a CU serves such loads at about one lane per clock
+            # whatever cache level they hit in (measured by tools/gather_roof.hip) -- far below what HBM, L2 or the vector ALU
+            # could take.  achieved = 16-byte lane accesses the kernel's queries need (counted by an instrumented pass) per
+            # second of kernel time; peak = the measured rate of a chain of dependent 64-byte gathers from an L2-resident table
+            # x 256 CUs; frac = achieved / peak.  The contract's HBM view of the same kernel is under "hbm".
+            "roofline": {"bound": "l1-gather", "bound_note": "per-lane gathers of different addresses: the CU's address/data path takes one lane x 16 B per clock "
+                                                             "(tools/gather_roof.hip); HBM, L2 and VALU roofs are not near",
                          "kernel": "k_" + dominant,
-                         "frac": (valu * lanes) if valu is not None and lanes is not None else None,
-                         "valu_issue_frac": valu, "valu_issue_frac_at_one_wave_rate": counters.get("valu_issue_frac_at_one_wave_rate"),
-                         "lane_frac": lanes, "wave_wait_frac": counters.get("wave_wait_frac"), "l2_hit_rate": counters.get("l2_hit_rate"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (fabric requests x 64 B)",
-                         "hbm_frac_measured": (traffic / counters["avg_launch_ms"] / 1e-3 / 1e9 / HBM_PEAK_GBS) if traffic and counters.get("avg_launch_ms") else None,
+                         "achieved": achieved_gather, "peak": peak_gather, "unit": "G lane-accesses/s (16 B each)", "frac": achieved_gather / peak_gather,
+                         "peak_source": peak_src, "lane_accesses_per_unit": lane_acc[dominant],
+                         "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (fabric requests x 64 B)",
+                         "hbm": {"achieved": achieved_hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_hbm / HBM_PEAK_GBS,
+                                 "note": "algorithmic bytes per unit x units / kernel time: counts gathers that L2 serves, so it may exceed the peak",
+                                 "measured_frac": (traffic / counters["avg_launch_ms"] / 1e-3 / 1e9 / HBM_PEAK_GBS) if traffic and counters.get("avg_launch_ms") else None,
+                                 "algorithmic_bytes_per_launch": per_unit[dominant] * units[dominant] / max(kn[dominant], 1),
+                                 "bytes_per_unit": per_unit[dominant]},
+                         "valu_issue_frac": valu, "lane_frac": lanes, "wave_wait_frac": counters.get("wave_wait_frac"), "l2_hit_rate": counters.get("l2_hit_rate"),
+                         "ta_busy_frac": counters.get("ta_busy_frac"), "td_busy_frac": counters.get("td_busy_frac"),
                          "counters_source": counters.get("source"), "counters_how": counters.get("how"),
                          "counters_measured_at": {k: counters.get(k) for k in ("git", "kernel_source_hash", "spp_per_pass", "avg_launch_ms")} if counters else None,
                          "stale": stale,
-                         "algorithmic_bytes_per_launch": per_unit[dominant] * units[dominant] / max(kn[dominant], 1),
-                         "bytes_per_unit": per_unit[dominant], "units_per_launch": units[dominant] / max(kn[dominant], 1),
+                         "units_per_launch": units[dominant] / max(kn[dominant], 1),
                          "avg_launch_ms": launch_s * 1e3},
         }
+        if rehearse:
+            # ranks shared GPUs and reduced through host memory: the code path ran, the figures mean nothing
+            out.update({"rehearsal": True, "metric": "REHEARSAL " + out["metric"], "rehearsal_value": out["value"], "value": None, "vs_baseline": None})
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out))

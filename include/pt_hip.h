@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PT_HIP_ABI_VERSION 1
+#define PT_HIP_ABI_VERSION 2
 
 typedef enum pt_status {
     PT_OK = 0,
@@ -176,6 +176,11 @@ typedef struct pt_stats {
     /* per-kernel device time (HIP events on the launch stream) and launch counts */
     double   kernel_ms[PT_MAX_KERNEL_STATS];
     uint64_t kernel_launches[PT_MAX_KERNEL_STATS];
+    /* PT_FLAG_COUNT_WORK only: those of nodes_fetched that the ordered traversal read from its copy of the top of the
+     * navigation tree in LDS instead of from memory */
+    uint64_t nodes_from_lds[3];
+    uint32_t samples_per_pass; /* samples of every pixel kept in flight per pass (the automatic choice when the caller gave 0) */
+    uint32_t passes;           /* passes the call took */
 } pt_stats;
 /* indices into kernel_ms / kernel_launches; PT_K_FINISH = the launches that run few paths for many iterations in one go
  * (the thinned-out tail of a pass; the last chains of specular bounces beyond max_bounce iterations);

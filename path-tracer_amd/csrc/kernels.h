@@ -132,8 +132,8 @@ struct PassArgs {
 
 // misc[0] = exact re-traces.  Counting builds only: for kernel class k (0 generate, 1 extend, 2 shadow) the u64 at
 // word 4 + 4k holds the node records fetched and the u64 at word 6 + 4k the triangle records fetched.  Words 16..19: the
-// queries of k_finish (two u64).
-constexpr int kMiscWords = 24;
+// queries of k_finish (two u64).  The u64 at word 20 + 2k: those of class k's node records that came from the LDS treelet.
+constexpr int kMiscWords = 32;
 
 // A ray that a wave-refill kernel handed back, in reference order: the whole query (plain-division rays, kDeferExact), or
 // bounded by `bound` when the ordered pass has already established that the nearest accepted triangle lies before it.
@@ -150,15 +150,17 @@ PTD void flush_counts(const NoCount&, uint32_t*, int) {}
 PTD void flush_counts(const Count& c, uint32_t* misc, int kernel_class) {
     if (!misc) return;
     misc += 4 * kernel_class;
-    uint32_t n = c.nodes, t = c.tris;
+    uint32_t n = c.nodes, t = c.tris, l = c.tops;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         n += uint32_t(__shfl_xor(int(n), off));
         t += uint32_t(__shfl_xor(int(t), off));
+        l += uint32_t(__shfl_xor(int(l), off));
     }
     if (lane_id() == 0) {
         atomicAdd(reinterpret_cast<unsigned long long*>(misc + 4), (unsigned long long)n);
         atomicAdd(reinterpret_cast<unsigned long long*>(misc + 6), (unsigned long long)t);
+        atomicAdd(reinterpret_cast<unsigned long long*>(misc - 4 * kernel_class + 20 + 2 * kernel_class), (unsigned long long)l);
     }
 }
 

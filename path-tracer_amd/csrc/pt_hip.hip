@@ -1585,10 +1585,13 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
             for (int k = 0; k < 3; ++k) {
                 st->nodes_fetched[k] += uint64_t(ws.h_misc()[4 + 4 * k]) | (uint64_t(ws.h_misc()[5 + 4 * k]) << 32);
                 st->tris_fetched[k] += uint64_t(ws.h_misc()[6 + 4 * k]) | (uint64_t(ws.h_misc()[7 + 4 * k]) << 32);
+                st->nodes_from_lds[k] += uint64_t(ws.h_misc()[20 + 2 * k]) | (uint64_t(ws.h_misc()[21 + 2 * k]) << 32);
             }
+            st->passes += 1;
         }
         if (int rc = tm.collect(st)) return rc;
     }
+    if (st) st->samples_per_pass = spp_pass;
     if (st) st->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
 }
@@ -1682,6 +1685,7 @@ int pt_hip_render_multi(pt_hip_scene* const* scenes, int n, const pt_render_para
             for (int j = 0; j < 3; ++j) {
                 st->nodes_fetched[j] += stats[k].nodes_fetched[j];
                 st->tris_fetched[j] += stats[k].tris_fetched[j];
+                st->nodes_from_lds[j] += stats[k].nodes_from_lds[j];
             }
             for (int j = 0; j < PT_MAX_KERNEL_STATS; ++j) {
                 st->kernel_ms[j] += stats[k].kernel_ms[j];

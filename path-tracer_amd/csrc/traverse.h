@@ -137,11 +137,13 @@ struct HitD {
 // instrumented kernel instantiations that produce the per-ray averages for the bandwidth model.
 struct NoCount {
     PTD void node() {}
+    PTD void top() {}
     PTD void tri() {}
 };
 struct Count {
-    uint32_t nodes = 0, tris = 0;
+    uint32_t nodes = 0, tops = 0, tris = 0;  // tops: those of `nodes` that were read from the LDS treelet
     PTD void node() { ++nodes; }
+    PTD void top() { ++tops; }
     PTD void tri() { ++tris; }
 };
 

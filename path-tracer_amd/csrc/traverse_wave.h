@@ -157,6 +157,7 @@ struct ClosestLane {
     template <class C>
     PTD void inner(const DevScene& sc, const Treelet& tl, DistStack& st, C& wc) {
         wc.node();
+        if (cur < tl.n) wc.top();
         uint4 c0, c1, c2, c3;
         nav_fetch(sc, tl, cur, c0, c1, c2, c3);
         const float inf = __builtin_huge_valf(), far = cull_bound();
@@ -292,6 +293,7 @@ struct AnyLane {
     template <class C>
     PTD void inner(const DevScene& sc, const Treelet& tl, AnyStack& st, C& wc) {
         wc.node();
+        if (cur < tl.n) wc.top();
         uint4 c0, c1, c2, c3;
         nav_fetch(sc, tl, cur, c0, c1, c2, c3);
         const bool g0 = bool(c0.w != kEmptyRef) & cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), tmin, far_end);

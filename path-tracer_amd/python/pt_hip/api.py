@@ -4,6 +4,7 @@ There is no CPU fallback: every call goes to the shared libraries, and a missing
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -58,12 +59,15 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64), ("exact_retraces", C.c_uint64),
-                ("nodes_fetched", C.c_uint64 * 3), ("tris_fetched", C.c_uint64 * 3), ("seconds", C.c_double), ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8)]
+                ("nodes_fetched", C.c_uint64 * 3), ("tris_fetched", C.c_uint64 * 3), ("seconds", C.c_double), ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8),
+                ("nodes_from_lds", C.c_uint64 * 3), ("samples_per_pass", C.c_uint32), ("passes", C.c_uint32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k in ("paths", "closest_rays", "any_rays", "exact_retraces", "seconds")}
         d["nodes_fetched"] = {n: self.nodes_fetched[i] for i, n in enumerate(("generate", "extend", "shadow"))}
         d["tris_fetched"] = {n: self.tris_fetched[i] for i, n in enumerate(("generate", "extend", "shadow"))}
+        d["nodes_from_lds"] = {n: self.nodes_from_lds[i] for i, n in enumerate(("generate", "extend", "shadow"))}
+        d["samples_per_pass"], d["passes"] = self.samples_per_pass, self.passes
         d["kernel_ms"] = {KERNEL_NAMES[i]: self.kernel_ms[i] for i in range(8) if self.kernel_launches[i]}
         d["kernel_launches"] = {KERNEL_NAMES[i]: self.kernel_launches[i] for i in range(8) if self.kernel_launches[i]}
         return d
@@ -102,9 +106,30 @@ def host_lib():
     return _host
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm ships its own copy of the HIP runtime (same soname as the system's).  A process that initialises both
+    copies loses the GPU in the second one ("No HIP GPUs are available"), so whichever of torch and this backend is loaded
+    first must decide for both: when torch is installed but not imported yet, its copy is loaded here, globally, and
+    libpt_hip.so's dependency then resolves to it -- as it does anyway when torch was imported first.  PT_HIP_SYSTEM_RUNTIME=1
+    keeps the system's runtime (for processes that never import torch)."""
+    if "torch" in sys.modules or os.environ.get("PT_HIP_SYSTEM_RUNTIME") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        lib = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(lib):
+            C.CDLL(lib, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
+
+
 def hip_lib():
     global _hip
     if _hip is None:
+        _share_torch_hip_runtime()
         L = C.CDLL(os.path.join(LIB_DIR, "libpt_hip.so"))
         L.pt_hip_last_error.restype = C.c_char_p
         L.pt_hip_init.argtypes = [C.c_int]

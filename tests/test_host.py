@@ -220,7 +220,7 @@ def test_headers_are_plain_c_and_the_binding_mirrors_their_layout(tmp_path):
 
 def test_hip_library_reports_errors_without_a_gpu_or_init():
     lib = api.hip_lib()
-    assert lib.pt_hip_abi_version() == 1
+    assert lib.pt_hip_abi_version() == 2
     h = C.c_void_p()
     rc = lib.pt_hip_scene_create(None, C.byref(h))
     assert rc < 0 and lib.pt_hip_last_error()

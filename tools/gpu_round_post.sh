@@ -2,7 +2,7 @@
 # Usage (on the GPU box, after tools/install_round.py has refreshed profiles/traffic.json): bash tools/gpu_round_post.sh <tag>
 # The two headline bench lines against the refreshed counters (so that they do not print "stale"), then the kernel trace,
 # the counter passes and the throughput of the 49 M triangle / 3840x2160 case.  Afterwards, here:
-#   cp gpurun_out/<tag>_bench_{library,veach}_fast.json profiles/r2_<letter>_bench_{library,veach}_fast.json
+#   cp gpurun_out/<tag>_bench_{library,veach}_fast.json profiles/r3_<letter>_bench_{library,veach}_fast.json
 #   python tools/uhd_summary.py <tag>_uhd <letter> <Mrays/s of the last line of gpurun_out/<tag>_uhd_pass.log>
 set -u
 TAG=$1

@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
-"""Copies the results of `tools/gpu_round.sh <tag>` from gpurun_out/ into profiles/ as r2_<letter>_*, replacing the files of
+"""Copies the results of `tools/gpu_round.sh <tag>` from gpurun_out/ into profiles/ as r3_<letter>_*, replacing the files of
 the previous letter, refreshes profiles/traffic.json from the counter passes and prints the figures the design notes quote.
 Usage: tools/install_round.py <tag> <new letter> <old letter>"""
 import glob, json, os, re, shutil, subprocess, sys
 tag, new, old = sys.argv[1:4]
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-pairs = [("%s_bench_%s.json" % (tag, k), "r2_%s_bench_%s.json" % (new, k)) for k in ("library_fast", "veach_fast", "veach_exact", "library_exact")]
-pairs += [("%s_prof_bench_library_fast.txt" % tag, "r2_%s_rocprof_bench_library_fast.txt" % new),
-          ("%s_prof_library_fast.txt" % tag, "r2_%s_rocprof_pmc_library512spp_fast.txt" % new),
-          ("%s_prof_veach_fast.txt" % tag, "r2_%s_rocprof_pmc_veach512spp_fast.txt" % new)]
+pairs = [("%s_bench_%s.json" % (tag, k), "r3_%s_bench_%s.json" % (new, k)) for k in ("library_fast", "veach_fast", "veach_exact", "library_exact")]
+pairs += [("%s_prof_bench_library_fast.txt" % tag, "r3_%s_rocprof_bench_library_fast.txt" % new),
+          ("%s_prof_library_fast.txt" % tag, "r3_%s_rocprof_pmc_library512spp_fast.txt" % new),
+          ("%s_prof_veach_fast.txt" % tag, "r3_%s_rocprof_pmc_veach512spp_fast.txt" % new)]
 if old != new:
-    for f in glob.glob(os.path.join(P, "r2_%s_bench_*.json" % old)) + glob.glob(os.path.join(P, "r2_%s_rocprof_*.txt" % old)):
+    for f in glob.glob(os.path.join(P, "r3_%s_bench_*.json" % old)) + glob.glob(os.path.join(P, "r3_%s_rocprof_*.txt" % old)):
         os.remove(f)
 for a, b in pairs:
     shutil.copy(os.path.join(G, a), os.path.join(P, b))
@@ -42,13 +42,13 @@ stamp = {"git": subprocess.check_output(["git", "-C", R, "rev-parse", "--short",
 t = {}
 for key, name, note in (("library-synth/fast", "library512spp", "gathers of 64-B lines are outside the guide's calibration (may read up to 2x low)"),
                         ("veach-mis/fast", "veach512spp", "the whole scene (0.3 MB of nodes and triangles) lives in L2, what reaches the fabric is queue traffic")):
-    rel = "profiles/r2_%s_rocprof_pmc_%s_fast.txt" % (new, name)
+    rel = "profiles/r3_%s_rocprof_pmc_%s_fast.txt" % (new, name)
     path = os.path.join(R, rel)
     t[key] = {}
     for kern in ("k_extend", "k_shadow", "k_generate", "k_shade"):
         sym = kern if kern == "k_shade" else kern + "_wave"
         v, n = row(path, "pmc3", sym), calls(path, sym)
-        p1, p2 = row(path, "pmc1", sym), row(path, "pmc2", sym)
+        p1, p2, p4 = row(path, "pmc1", sym), row(path, "pmc2", sym), row(path, "pmc4", sym)
         # cycles of the launches: GRBM_GUI_ACTIVE over the 8 XCDs, scaled from its pass to this one; when that pass was
         # disturbed (the counter then runs far ahead of the kernel's own busy cycles) SQ_BUSY_CYCLES over the 32 shader
         # engines of the same pass as the instruction count
@@ -71,13 +71,17 @@ for key, name, note in (("library-synth/fast", "library512spp", "gathers of 64-B
             # share of the resident waves' time spent waiting (memory, LDS, dependencies): SQ_WAIT_ANY / SQ_WAVE_CYCLES
             "wave_wait_frac": round(p2[7] / p1[8] * (p1[0] / p2[0]), 3),
             "l2_hit_rate": round(v[4] / (v[4] + v[5]), 3),
+            # busy share of the 256 texture-address and texture-data units over the launches (cycles of their own pass:
+            # GRBM_GUI_ACTIVE over the 8 XCDs); "busy" includes the time a unit waits for the cache behind it
+            "ta_busy_frac": round(p4[3] / 256 / (p4[1] / 8), 3), "td_busy_frac": round(p4[5] / 256 / (p4[1] / 8), 3),
+            "td_stalled_by_cache_frac": round(p4[4] / 256 / (p4[1] / 8), 3),
             "avg_launch_ms": round(v[0] / n * 1e-3, 4), **stamp}
         print(key, kern, t[key][kern]["bytes_per_launch"], t[key][kern]["valu_issue_frac"], t[key][kern]["lanes_per_valu_inst_frac"], t[key][kern]["l2_hit_rate"])
 json.dump(t, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 for k in ("library_fast", "veach_fast", "veach_exact", "library_exact"):
-    d = json.load(open(os.path.join(P, "r2_%s_bench_%s.json" % (new, k))))
+    d = json.load(open(os.path.join(P, "r3_%s_bench_%s.json" % (new, k))))
     r = d["roofline"]
     print(k, "Mrays/s %.0f" % d["value"], "samples/s %.3g" % d["samples_per_s"], "ms/step %.0f" % d["ms_per_step"], "| roofline", r["kernel"],
-          "frac", r["frac"], "stale", r["stale"], "avg launch %.3f ms" % r["avg_launch_ms"], "bytes/unit %.0f" % r["bytes_per_unit"], "units/launch %.3g" % r["units_per_launch"],
+          "frac", r["frac"], "stale", r["stale"], "avg launch %.3f ms" % r["avg_launch_ms"], "lane accesses/unit %.1f" % r["lane_accesses_per_unit"], "bytes/unit %.0f" % r["hbm"]["bytes_per_unit"], "units/launch %.3g" % r["units_per_launch"],
           "| cpu", d.get("cpu_baseline", {}).get("value"))
-print(open(os.path.join(P, "r2_%s_rocprof_bench_library_fast.txt" % new)).read().split("\n")[2])
+print(open(os.path.join(P, "r3_%s_rocprof_bench_library_fast.txt" % new)).read().split("\n")[2])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Prepends the derived figures of the 49 M triangle / 3840x2160 profile (tools/gpu_uhd_prof.sh) to its text summary and
-writes profiles/r2_<letter>_rocprof_pmc_library49M_uhd_fast.txt.
+writes profiles/r3_<letter>_rocprof_pmc_library49M_uhd_fast.txt.
 Usage: tools/uhd_summary.py <tag> <letter> <Mrays/s outside the profiler>"""
 import os, re, sys
 tag, letter, mrays = sys.argv[1:4]
@@ -23,7 +23,7 @@ for sec in src.split("== ")[1:]:
             for k, v in zip(names, l.split()[2:]):
                 c.setdefault(k, float(v))
             break
-ref = os.path.join(R, "profiles", "r2_%s_rocprof_pmc_library512spp_fast.txt" % letter)
+ref = os.path.join(R, "profiles", "r3_%s_rocprof_pmc_library512spp_fast.txt" % letter)
 paths = re.search(r"(\d+) rays", src)
 cyc = c["GRBM_GUI_ACTIVE"] / 8
 issue = c["SQ_INSTS_VALU"] * 2 / (1024 * cyc)
@@ -55,6 +55,6 @@ hdr += """# Reading: the drop between 1.6 M and 49 M triangles is not an HBM-ban
 # costs 1.5x the traversal instructions at fewer lanes per instruction; and every second L2 request misses, which six waves
 # per SIMD cover even less: the VALU issue share falls by a quarter.
 """
-out = os.path.join(R, "profiles", "r2_%s_rocprof_pmc_library49M_uhd_fast.txt" % letter)
+out = os.path.join(R, "profiles", "r3_%s_rocprof_pmc_library49M_uhd_fast.txt" % letter)
 open(out, "w").write(hdr + src)
 print(hdr)
