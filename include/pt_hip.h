@@ -234,12 +234,14 @@ int pt_hip_occluded(pt_hip_scene* scene, const pt_ray* rays, size_t n, uint8_t* 
 int pt_hip_intersect_device(pt_hip_scene* scene, const pt_ray* d_rays, size_t n, pt_hit* d_hits, int mode, float* kernel_ms);
 int pt_hip_occluded_device(pt_hip_scene* scene, const pt_ray* d_rays, size_t n, uint8_t* d_occluded, int mode, float* kernel_ms);
 
-/* No counterpart in the reference.  pt_hip_intersect_device for callers that cannot allocate device memory (code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): same kernels and results, but the per-shard
- * fetch counters of the ordered traversal live in a fixed array inside the library image (one copy per GPU, held until the
- * process ends) instead of a buffer the handle grows on demand, no events are created (hence no kernel_ms), and the call
- * makes no hipMalloc / hipFree.  At most PT_NOALLOC_MAX_RAYS rays per call (PT_ERR_LIMIT beyond that).  All calls on one
- * GPU share the array: calls that overlap on one GPU (from several threads or processes' streams) race.  Synchronous. */
+/* No counterpart in the reference.  pt_hip_intersect_device for callers that cannot allocate device memory (tight serving
+ * loops, harnesses that forbid hipMalloc): same kernels and results, but the per-shard fetch counters of the ordered
+ * traversal live in a fixed array inside the library image (one copy per GPU and process, held until the process ends)
+ * instead of a buffer the handle grows on demand, no events are created (hence no kernel_ms), and the call makes no
+ * hipMalloc / hipFree.  At most PT_NOALLOC_MAX_RAYS rays per call (PT_ERR_LIMIT beyond that).  All calls on one GPU share
+ * the array; the library serialises them (threads that call it for handles on the same GPU wait for each other).
+ * Synchronous: the work runs on the handle's own stream and the call returns when it is done, so it is NOT for code under
+ * HIP graph capture (a capturing stream cannot be synchronised, and this work is not on it). */
 #define PT_NOALLOC_MAX_RAYS 67108864u /* 16384 shards of 4096 rays: 64 KB of counters */
 int pt_hip_intersect_device_noalloc(pt_hip_scene* scene, const pt_ray* d_rays, size_t n, pt_hit* d_hits, int mode);
 

@@ -35,7 +35,7 @@ struct PathQ {
 };
 
 struct HitQ {
-    float4* h0;       // {bits(path index inside the shard), bits(prim), u, v}
+    float4* h0;       // {bits(path index inside the shard), bits(primitive word: index + kPrim* flags), u, v}
     float4* h1;       // {bits(px | py << 16), bits(dim | bounce << 10 | frame << 16), t, 0}  (copied so that shade can
                       //  start its Sobol' and triangle-record reads without waiting for the path state)
     uint32_t* count;  // [shard]
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene sc, const float4*
         const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
         HitD h;
         closest_exact(sc, ray, h, s_stack + threadIdx.x, wc);
-        hits[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+        hits[i] = make_float4(as_f(uint32_t(prim_index(h.prim))), h.t, h.u, h.v);
     }
     flush_counts(wc, misc, 1);
 }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_occluded(DevScene sc, const float4* 
         int32_t fp = -1;
         const bool hit = any_exact(sc, ray, fp, s_stack + threadIdx.x, wc);
         occ[i] = hit ? 1 : 0;
-        if (first_prim) first_prim[i] = hit ? fp : -1;
+        if (first_prim) first_prim[i] = hit ? prim_index(fp) : -1;
     }
     flush_counts(wc, misc, 2);
 }
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
                 complete(t, h.u, h.v, it);
                 out = it.n;
             } else {
-                out = surface_material(sc, t, uint32_t(h.prim), h.u, h.v).kd;
+                out = surface_material(sc, t, h.u, h.v).kd;
             }
             alive = false;
         }
@@ -328,7 +328,7 @@ struct GenerateIo {
                     complete(t, h.u, h.v, it);
                     out = it.n;
                 } else {
-                    out = surface_material(sc, t, uint32_t(h.prim), h.u, h.v).kd;
+                    out = surface_material(sc, t, h.u, h.v).kd;
                 }
                 alive = false;
             }
@@ -563,7 +563,7 @@ struct BatchClosestIo {
     PTD void commit(const DevScene&, uint32_t shard, bool fin, uint32_t j, const HitD& h, bool defer, float bound, const Carry&, const V3&, const V3&) const {
         if (!fin) return;
         const size_t i = size_t(shard) * kShard + j;
-        hits[i] = defer ? make_float4(as_f(kBatchDeferred), bound, 0.0f, 0.0f) : make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+        hits[i] = defer ? make_float4(as_f(kBatchDeferred), bound, 0.0f, 0.0f) : make_float4(as_f(uint32_t(prim_index(h.prim))), h.t, h.u, h.v);
     }
 };
 
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_fix(DevScene sc, const flo
             const RayD ray{V3{r0.x, r0.y, r0.z}, V3{r0.w, r1.x, r1.y}, r1.z, r1.w};
             HitD h;
             trace_deferred(sc, ray, m.y, h, s_stack + threadIdx.x, misc, wc);
-            hits[i] = make_float4(as_f(uint32_t(h.prim)), h.t, h.u, h.v);
+            hits[i] = make_float4(as_f(uint32_t(prim_index(h.prim))), h.t, h.u, h.v);
         }
     }
     flush_counts(wc, misc, 1);
@@ -685,7 +685,7 @@ PTD void shade_hit(const DevScene& sc, const PassArgs& pa, const float4 h0, cons
     Surf it;
     complete(tr, h0.z, h0.w, it);
     const V3 wo = -rd;
-    const Mat m = surface_material(sc, tr, prim, h0.z, h0.w);
+    const Mat m = surface_material(sc, tr, h0.z, h0.w);
 
     // emitted radiance with MIS against light sampling (src/integrator.cpp:58-69)
     if (tr.light_id() >= 0) {
@@ -1123,8 +1123,9 @@ __global__ void k_div_selftest(uint64_t seed, uint32_t per_thread, unsigned long
     for (uint32_t i = 0; i < per_thread; ++i) {
         const uint64_t r = next();
         uint32_t nb = uint32_t(r), db = uint32_t(r >> 32);
-        // exponents: numerator 2^-60 .. 2^49, divisor 2^-29 .. 2^1 (pairs outside the range the traversal uses are skipped)
-        const uint32_t ne = 67u + (nb >> 23) % 110u, de = 98u + (db >> 23) % 31u;
+        // exponents: numerator 2^-60 .. 2^60, divisor 2^-30 .. 2^30 -- all that make_pre / box_decide let through to
+        // div_refine (pairs outside that range, or with a quotient below kTinyQ, are skipped by div5_mismatch)
+        const uint32_t ne = 67u + (nb >> 23) % 120u, de = 97u + (db >> 23) % 60u;
         nb = (nb & 0x807fffffu) | (ne << 23);
         db = (db & 0x807fffffu) | (de << 23);
         const uint32_t kind = uint32_t(next() % 8u);

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <string>
 #include <thread>
@@ -53,7 +54,9 @@ constexpr uint32_t kNoAllocShards = PT_NOALLOC_MAX_RAYS / kShard;
 static_assert(kNoAllocShards * kShard == PT_NOALLOC_MAX_RAYS && kNoAllocShards <= kMaxGridY, "whole shards, one launch");
 static __device__ __align__(256) uint32_t scratch[kNoAllocShards];
 constexpr int kMaxDevices = 64;
-uint32_t* g_noalloc_fetch[kMaxDevices] = {};
+std::atomic<uint32_t*> g_noalloc_fetch[kMaxDevices] = {};
+std::mutex g_noalloc_setup;              // guards the first hipGetSymbolAddress of a device
+std::mutex g_noalloc_call[kMaxDevices];  // one call at a time per GPU: every call on a GPU uses that GPU's one array
 
 int fail(int code, const std::string& msg) {
     g_error = msg;
@@ -206,6 +209,9 @@ struct pt_hip_scene {
     int32_t* tile_pos = nullptr;
     uint32_t split_key = 0, split_tiles = 0;
     uint64_t split_pixels = 0;
+    // handles that render at the same time on this handle's GPU (set by pt_hip_render_multi for the length of its call):
+    // the automatic pass size gives each an equal share of the free device memory
+    uint32_t sharing = 1;
 };
 
 namespace {
@@ -378,6 +384,9 @@ bool unreliable_triangle(const float* e1, const float* e2) {
     return area2 < 0x1p-10 * scale && area2 + 0x1p-19 * scale >= 1e-5;
 }
 
+// mesh has normals and this face's first normal index is non-zero (include/pt/mesh.h:37-39)
+inline bool tri_has_normals(const pt_scene_desc* d, uint32_t prim) { return d->n_normals != 0 && d->ni && d->ni[3 * size_t(prim)] != 0; }
+
 int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     DevScene& dev = s->dev;
     PhaseClock clk;
@@ -437,11 +446,12 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
                 }
                 for (uint32_t k = 0; k < b.count; ++k) {
                     const uint32_t prim = d->prim_ids[b.first + k];
+                    const uint32_t prim_word = prim | (tri_has_normals(d, prim) ? kPrimHasNormals : 0u) | (d->light_id[prim] >= 0 ? kPrimEmitter : 0u);
                     const float* p0 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 0] - 1);
                     const float* p1 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 1] - 1);
                     const float* p2 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 2] - 1);
                     float fp;
-                    std::memcpy(&fp, &prim, 4);
+                    std::memcpy(&fp, &prim_word, 4);
                     float4* o = h + 3 * size_t(k);
                     o[0] = make_float4(p0[0], p0[1], p0[2], fp);
                     o[1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.0f);
@@ -600,7 +610,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     // shading records: one 128-byte record per triangle, one 96-byte record per light
     {
         auto vert = [&](uint32_t prim, int k) { return d->verts + 3 * size_t(d->vi[3 * size_t(prim) + k] - 1); };
-        auto has_normals = [&](uint32_t prim) { return d->n_normals != 0 && d->ni && d->ni[3 * size_t(prim)] != 0; };
+        auto has_normals = [&](uint32_t prim) { return tri_has_normals(d, prim); };
         auto normal = [&](uint32_t prim, int k) { return d->normals + 3 * size_t(d->ni[3 * size_t(prim) + k] - 1); };
         for (uint32_t t = 0; t < d->n_tris; ++t)
             if (has_normals(t))
@@ -611,7 +621,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             std::memcpy(&f, &u, 4);
             return f;
         };
-        auto pack_geometry = [&](uint32_t prim, float4* o) {  // v0 v1 v2 n0 n1 n2 in 4.5 float4
+        auto pack_geometry = [&](uint32_t prim, float4* o) {  // v0 v1 v2 n0 n1 n2 in 4.5 float4 (light records)
             const float *a = vert(prim, 0), *b = vert(prim, 1), *c = vert(prim, 2);
             float n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (has_normals(prim))
@@ -622,23 +632,32 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             o[3] = make_float4(n[3], n[4], n[5], n[6]);
             o[4] = make_float4(n[7], n[8], 0.0f, 0.0f);
         };
+        if (d->n_tris > kPrimMask) return fail(PT_ERR_LIMIT, "more than 2^29-1 triangles");
         if (int rc = fill_upload<float4>(
                 s, d->n_tris, [](size_t u) { return size_t(kTriRecVec4) * u; }, &dev.trec, [&](size_t ti_, float4* o) {
                     const uint32_t t = uint32_t(ti_);
-                    pack_geometry(t, o);
+                    const float *a = vert(t, 0), *b = vert(t, 1), *c = vert(t, 2);
+                    float n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    if (has_normals(t))
+                        for (int k = 0; k < 3; ++k) std::memcpy(n + 3 * k, normal(t, k), 12);
                     uint32_t flags = has_normals(t) ? kTriHasNormals : 0u;
                     if (d->n_uvs != 0 && d->ti && d->ti[3 * size_t(t)] != 0) flags |= kTriHasUvs;
                     const int32_t lid = d->light_id[t];
-                    o[4].z = bits(flags);
-                    o[4].w = bits(uint32_t(lid));
                     const pt_material& m = d->mats[d->mat_id[t]];
-                    o[5] = make_float4(m.kd[0], m.kd[1], m.kd[2], m.ns);
-                    o[6] = make_float4(m.ks[0], m.ks[1], m.ks[2], bits(uint32_t(m.tex)));
-                    o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    float lemit[3] = {0.0f, 0.0f, 0.0f}, inv_area = 0.0f;
                     if (lid >= 0) {
                         const pt_light& l = d->lights[lid];
-                        o[7] = make_float4(l.lemit[0], l.lemit[1], l.lemit[2], float(1.0 / double(l.area)));
+                        std::memcpy(lemit, l.lemit, 12);
+                        inv_area = float(1.0 / double(l.area));
                     }
+                    o[0] = make_float4(a[0], a[1], a[2], b[0]);
+                    o[1] = make_float4(b[1], b[2], c[0], c[1]);
+                    o[2] = make_float4(c[2], bits(flags), bits(uint32_t(lid)), bits(uint32_t(m.tex)));
+                    o[3] = make_float4(m.kd[0], m.kd[1], m.kd[2], m.ns);
+                    o[4] = make_float4(m.ks[0], m.ks[1], m.ks[2], inv_area);
+                    o[5] = make_float4(n[0], n[1], n[2], n[3]);
+                    o[6] = make_float4(n[4], n[5], n[6], n[7]);
+                    o[7] = make_float4(lemit[0], lemit[1], lemit[2], n[8]);
                 }))
             return rc;
         std::vector<float4> lrec(size_t(kLightRecVec4) * d->n_lights);
@@ -1123,10 +1142,12 @@ int bind_default() {
 
 // this device's copy of the static fetch counters (pt_hip_intersect_device_noalloc); the device must be current
 int noalloc_address(int device) {
-    if (device < kMaxDevices && !g_noalloc_fetch[device]) {
+    if (device >= kMaxDevices) return PT_OK;
+    std::lock_guard<std::mutex> lock(g_noalloc_setup);  // handles are created from several threads
+    if (!g_noalloc_fetch[device].load(std::memory_order_acquire)) {
         uint32_t* p = nullptr;
         HIP_TRY(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch)));
-        g_noalloc_fetch[device] = p;
+        g_noalloc_fetch[device].store(p, std::memory_order_release);
     }
     return PT_OK;
 }
@@ -1452,8 +1473,11 @@ int pt_hip_intersect_device_noalloc(pt_hip_scene* s, const pt_ray* d_rays, size_
     if (n > PT_NOALLOC_MAX_RAYS)
         return fail(PT_ERR_LIMIT, "pt_hip_intersect_device_noalloc takes at most " + std::to_string(PT_NOALLOC_MAX_RAYS) + " rays per call (" +
                                       std::to_string(n) + " given): split the batch or use pt_hip_intersect_device");
-    uint32_t* fetch = g_device < kMaxDevices ? g_noalloc_fetch[g_device] : nullptr;
+    uint32_t* fetch = g_device < kMaxDevices ? g_noalloc_fetch[g_device].load(std::memory_order_acquire) : nullptr;
     if (!fetch) return fail(PT_ERR_NOT_INIT, "no static work buffer on this device (device ordinal beyond " + std::to_string(kMaxDevices - 1) + ")");
+    // Several handles may live on one GPU, each driven by its own host thread, and they all share this GPU's array: the
+    // call is synchronous anyway, so it holds the GPU's lock from the clearing of the counters to the end of the kernels.
+    std::lock_guard<std::mutex> lock(g_noalloc_call[g_device]);
     // the buffer keeps the previous call's counters: clear the part this call uses
     if (mode == PT_TRAVERSE_FAST) HIP_TRY(hipMemsetAsync(fetch, 0, size_t(blocks(uint32_t(n), kShard)) * sizeof(uint32_t), g_stream));
     if (int rc = launch_intersect(s, d_rays, n, d_hits, mode, fetch)) return rc;
@@ -1526,12 +1550,14 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
         // passes are faster (measured at 1280x720: 8 M slots 1.5, 64 M 2.5, 128 M 2.7, 256 M 2.8 Grays/s on a 1.6 M
         // triangle interior; with the later kernels 128 M 3.5, 236 M 3.7, 472 M 3.8); 537 M slots are 120 GB of the 288 GB.
         // Less when the device is short of memory.
-        uint64_t slots = kAutoSlots;
+        const uint32_t sharing = std::max(1u, s->sharing);
+        uint64_t slots = kAutoSlots / sharing;
         if (s->ws.cap_slots < slots) {
             size_t free_b = 0, total_b = 0;
             HIP_TRY(hipMemGetInfo(&free_b, &total_b));
             const uint64_t held = uint64_t(s->ws.cap_slots) * kBytesPerSlot;
-            slots = std::min<uint64_t>(slots, (uint64_t(free_b) + held) * 6 / 10 / kBytesPerSlot);
+            // handles that share the GPU all read the same free figure before any of them has allocated
+            slots = std::min<uint64_t>(slots, (uint64_t(free_b) / sharing + held) * 6 / 10 / kBytesPerSlot);
         }
         spp_pass = uint32_t(std::min<uint64_t>(0xffffu, std::max<uint64_t>(1, slots / slots_per_sample)));  // 16-bit frame field of the path state
     }
@@ -1542,7 +1568,15 @@ int pt_hip_render_device(pt_hip_scene* s, const pt_render_params* params, float*
     }
     if (slots_per_sample * spp_pass > 0x7fffffffull) return fail(PT_ERR_LIMIT, "samples_per_pass too large for this resolution");
     if (spp_pass > 0xffffu) return fail(PT_ERR_LIMIT, "samples_per_pass must be < 65536");
-    if (int rc = ws_reserve(s->ws, uint32_t(slots_per_sample * spp_pass), spp_pass)) return rc;
+    for (;;) {
+        const int rc = ws_reserve(s->ws, uint32_t(slots_per_sample * spp_pass), spp_pass);
+        if (rc == PT_OK) break;
+        // the automatic choice did not fit after all (other users of the GPU): smaller passes instead of giving up
+        const bool out_of_memory = hipGetLastError() == hipErrorOutOfMemory || g_error.find(hipGetErrorString(hipErrorOutOfMemory)) != std::string::npos;
+        if (p.samples_per_pass != 0 || spp_pass <= 1 || !out_of_memory) return rc;
+        ws_release(s->ws);
+        spp_pass = (spp_pass + 1) / 2;
+    }
     Workspace& ws = s->ws;
     HIP_TRY(hipMemsetAsync(d_film, 0, sizeof(float) * 4 * size_t(W + 4) * size_t(H + 4), g_stream));
     s->events.used = 0;  // an earlier call that failed half-way may have left recorded pairs behind
@@ -1646,6 +1680,12 @@ int pt_hip_render_multi(pt_hip_scene* const* scenes, int n, const pt_render_para
         if (int rc = check_ready(scenes[k])) return rc;
         if (int rc = stage_reserve(scenes[k], 3, bytes, &d_film[k])) return rc;
     }
+    // handles on the same GPU share its free memory when they choose their pass size
+    for (int k = 0; k < n; ++k) {
+        uint32_t same = 0;
+        for (int j = 0; j < n; ++j) same += scenes[j]->device == scenes[k]->device ? 1u : 0u;
+        scenes[k]->sharing = same;
+    }
     // one host thread per handle, as the single-GPU entry point is driven
     std::vector<std::thread> th;
     for (int k = 0; k < n; ++k)
@@ -1661,6 +1701,7 @@ int pt_hip_render_multi(pt_hip_scene* const* scenes, int n, const pt_render_para
             if (rcs[k]) errs[k] = g_error;
         });
     for (std::thread& t : th) t.join();
+    for (int k = 0; k < n; ++k) scenes[k]->sharing = 1;
     for (int k = 0; k < n; ++k)
         if (rcs[k]) return fail(rcs[k], "GPU " + std::to_string(scenes[k]->device) + ": " + errs[k]);
     // the one reduction of the frame (src/block.cpp:102-110): films are summed on the first handle's GPU

@@ -29,13 +29,22 @@ constexpr uint32_t kTreeletMax = 1024;
 
 // Shading record of one triangle: exactly one 128-byte line, 8 x float4, everything the shade step needs about the
 // surface it hit (the reference chases Triangle* -> TriangleMesh -> index arrays -> vertex arrays, and Material*,
-// AreaLight*: include/pt/shape.h:58-63, include/pt/mesh.h:31-55):
-//   r0 {v0.x v0.y v0.z v1.x}  r1 {v1.y v1.z v2.x v2.y}  r2 {v2.z n0.x n0.y n0.z}  r3 {n1.x n1.y n1.z n2.x}
-//   r4 {n2.y n2.z bits(flags) bits(light_id)}  r5 {kd.r kd.g kd.b ns}  r6 {ks.r ks.g ks.b bits(tex)}
-//   r7 {lemit.r lemit.g lemit.b inv_area}   (zero when the triangle is not an emitter)
+// AreaLight*: include/pt/shape.h:58-63, include/pt/mesh.h:31-55).  What every hit needs comes first, so that a hit on a
+// triangle without vertex normals that is no emitter reads five of the eight quarters:
+//   r0 {v0.x v0.y v0.z v1.x}  r1 {v1.y v1.z v2.x v2.y}  r2 {v2.z bits(flags) bits(light_id) bits(tex)}
+//   r3 {kd.r kd.g kd.b ns}  r4 {ks.r ks.g ks.b inv_area}
+//   r5 {n0.x n0.y n0.z n1.x}  r6 {n1.y n1.z n2.x n2.y}  r7 {lemit.r lemit.g lemit.b n2.z}
+// (lemit and inv_area are zero when the triangle is not an emitter, the normals when it has none).
 constexpr uint32_t kTriHasNormals = 1u;  // mesh has normals and this face's first normal index is non-zero (mesh.h:37-39)
 constexpr uint32_t kTriHasUvs = 2u;      // same for texture coordinates (mesh.h:46-48)
 constexpr int kTriRecVec4 = 8;
+// The primitive word of a leaf-array record (and of a hit-list entry) carries the triangle's index in its low bits and,
+// above them, which of the optional quarters of its shading record a hit on it needs -- known together with the hit, so
+// that the shade step can ask for exactly those in one round of loads.  Bit 31 stays clear: -1 means "no hit".
+constexpr uint32_t kPrimMask = (1u << 29) - 1u;
+constexpr uint32_t kPrimHasNormals = 1u << 29;
+constexpr uint32_t kPrimEmitter = 1u << 30;
+PTD int32_t prim_index(int32_t word) { return word < 0 ? word : int32_t(uint32_t(word) & kPrimMask); }
 
 // Sampling record of one area light, 6 x float4 (AreaLight + its Triangle, src/light.cpp:10-33, src/shape.cpp:95-113):
 //   l0 {v0.x v0.y v0.z v1.x}  l1 {v1.y v1.z v2.x v2.y}  l2 {v2.z n0.x n0.y n0.z}  l3 {n1.x n1.y n1.z n2.x}

@@ -10,28 +10,38 @@ namespace ptd {
 
 // ---------------------------------------------------------------------------------------------------- records
 
-// One triangle's shading record, loaded as 8 independent 16-byte reads of one 128-byte line.
+// One triangle's shading record, loaded as independent 16-byte reads of one 128-byte line: five for every hit, the
+// quarters with the vertex normals and the emitted radiance only when the hit's primitive word asks for them.
 struct TriRec {
     float4 r[kTriRecVec4];
-    PTD void load(const DevScene& sc, uint32_t prim) {
-        const float4* p = sc.trec + size_t(prim) * kTriRecVec4;
+    uint32_t index;  // the triangle's number (the primitive word without its flag bits)
+    PTD void load(const DevScene& sc, uint32_t prim_word) {
+        index = prim_word & kPrimMask;
+        const float4* p = sc.trec + size_t(index) * kTriRecVec4;
 #pragma unroll
-        for (int k = 0; k < kTriRecVec4; ++k) r[k] = p[k];
+        for (int k = 0; k < 5; ++k) r[k] = p[k];
+        const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        r[5] = r[6] = r[7] = zero;
+        if (prim_word & kPrimHasNormals) {
+            r[5] = p[5];
+            r[6] = p[6];
+        }
+        if (prim_word & (kPrimHasNormals | kPrimEmitter)) r[7] = p[7];
     }
     PTD V3 v0() const { return V3{r[0].x, r[0].y, r[0].z}; }
     PTD V3 v1() const { return V3{r[0].w, r[1].x, r[1].y}; }
     PTD V3 v2() const { return V3{r[1].z, r[1].w, r[2].x}; }
-    PTD V3 n0() const { return V3{r[2].y, r[2].z, r[2].w}; }
-    PTD V3 n1() const { return V3{r[3].x, r[3].y, r[3].z}; }
-    PTD V3 n2() const { return V3{r[3].w, r[4].x, r[4].y}; }
-    PTD uint32_t flags() const { return as_u(r[4].z); }
-    PTD int32_t light_id() const { return int32_t(as_u(r[4].w)); }
-    PTD V3 kd() const { return V3{r[5].x, r[5].y, r[5].z}; }
-    PTD float ns() const { return r[5].w; }
-    PTD V3 ks() const { return V3{r[6].x, r[6].y, r[6].z}; }
-    PTD int32_t tex() const { return int32_t(as_u(r[6].w)); }
+    PTD uint32_t flags() const { return as_u(r[2].y); }
+    PTD int32_t light_id() const { return int32_t(as_u(r[2].z)); }
+    PTD int32_t tex() const { return int32_t(as_u(r[2].w)); }
+    PTD V3 kd() const { return V3{r[3].x, r[3].y, r[3].z}; }
+    PTD float ns() const { return r[3].w; }
+    PTD V3 ks() const { return V3{r[4].x, r[4].y, r[4].z}; }
+    PTD float inv_area() const { return r[4].w; }
+    PTD V3 n0() const { return V3{r[5].x, r[5].y, r[5].z}; }
+    PTD V3 n1() const { return V3{r[5].w, r[6].x, r[6].y}; }
+    PTD V3 n2() const { return V3{r[6].z, r[6].w, r[7].w}; }
     PTD V3 lemit() const { return V3{r[7].x, r[7].y, r[7].z}; }
-    PTD float inv_area() const { return r[7].w; }
 };
 
 struct LightRec {
@@ -116,9 +126,9 @@ struct Mat {
     float ns;
 };
 // Material::getBaseColor(uv) (src/material.cpp:9-16) folded into the material the shade step works with
-PTD Mat surface_material(const DevScene& sc, const TriRec& t, uint32_t prim, float u, float v) {
+PTD Mat surface_material(const DevScene& sc, const TriRec& t, float u, float v) {
     Mat m{t.kd(), t.ks(), t.ns()};
-    if (t.tex() >= 0) m.kd = tex_sample(sc, sc.textures[t.tex()], surface_uv(sc, prim, t.flags(), u, v));
+    if (t.tex() >= 0) m.kd = tex_sample(sc, sc.textures[t.tex()], surface_uv(sc, t.index, t.flags(), u, v));
     return m;
 }
 PTD bool is_mirror(const Mat& m) { return m.ks.x > 999.0f || m.ks.y > 999.0f || m.ks.z > 999.0f; }

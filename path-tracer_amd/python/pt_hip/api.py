@@ -191,7 +191,7 @@ def build_bvh(verts, vi):
 
 def build_bvh_gpu(verts, vi, device=0):
     """The same tree from pt_hip_build_bvh (segmented-scan sweep-SAH on the GPU)."""
-    init(device)
+    _default_gpu(device)
     verts = np.ascontiguousarray(verts, np.float32)
     vi = np.ascontiguousarray(vi, np.uint32)
     L = hip_lib()
@@ -289,6 +289,15 @@ def init(device=0):
     if _inited is None:
         _chk(hip_lib().pt_hip_init(device))
         _inited = device
+
+
+def _default_gpu(device):
+    """For the calls that take no handle (tree builder, probes, self test): they run on the process's default GPU, so an
+    explicit ordinal other than that one is refused instead of being silently ignored."""
+    init(device)
+    if device != _inited:
+        raise PtError("this call runs on the default GPU of the process (%d, set by the first pt_hip_init); %d was asked for: "
+                      "use a Scene(device=...) handle for work on another GPU" % (_inited, device))
 
 
 class Scene:
@@ -406,7 +415,7 @@ def device_count():
 
 
 def selftest_division(pairs, seed=1, device=0):
-    init(device)
+    _default_gpu(device)
     bad = C.c_uint64(0)
     _chk(hip_lib().pt_hip_selftest_division(pairs, seed, C.byref(bad)))
     return bad.value
@@ -414,7 +423,7 @@ def selftest_division(pairs, seed=1, device=0):
 
 def probe_box(boxes6, rays, device=0):
     """AABB::intersect for explicit (box, ray) pairs as the kernels evaluate it: n x 6 boxes, n x 8 rays -> uint8[n]."""
-    init(device)
+    _default_gpu(device)
     boxes6, rays = np.ascontiguousarray(boxes6, np.float32), np.ascontiguousarray(rays, np.float32)
     out = np.zeros(len(rays), np.uint8)
     _chk(hip_lib().pt_hip_probe_box(_p(boxes6, c_f32p), rays.ctypes.data_as(C.c_void_p), len(rays), _p(out, c_u8p)))
@@ -423,7 +432,7 @@ def probe_box(boxes6, rays, device=0):
 
 def probe_triangle(tri9, rays, device=0):
     """Triangle::intersect for explicit (triangle, ray) pairs: n x 9 corners, n x 8 rays -> (uint8[n], float32[n, 3] t u v)."""
-    init(device)
+    _default_gpu(device)
     tri9, rays = np.ascontiguousarray(tri9, np.float32), np.ascontiguousarray(rays, np.float32)
     hit, tuv = np.zeros(len(rays), np.uint8), np.zeros((len(rays), 3), np.float32)
     _chk(hip_lib().pt_hip_probe_triangle(_p(tri9, c_f32p), rays.ctypes.data_as(C.c_void_p), len(rays), _p(hit, c_u8p), _p(tuv, c_f32p)))
@@ -432,7 +441,7 @@ def probe_triangle(tri9, rays, device=0):
 
 def probe_math(x, y, device=0):
     """The shading code's sin(x), cos(x) and x ** y for explicit float32 operands -> float32[n, 3]."""
-    init(device)
+    _default_gpu(device)
     x, y = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32)
     out = np.zeros((len(x), 3), np.float32)
     _chk(hip_lib().pt_hip_probe_math(_p(x, c_f32p), _p(y, c_f32p), len(x), _p(out, c_f32p)))
