@@ -3,6 +3,7 @@
 #include <cstring>
 #include <exception>
 #include <string>
+#include <vector>
 
 #include "pt_host_internal.h"
 
@@ -85,5 +86,43 @@ int pt_host_make_lights(const float* verts, const uint32_t* vi, uint32_t n_tris,
 }
 
 void pt_host_filter_table(float* out33) { filter_table(out33); }
+
+int pt_host_save_png(const char* path, const float* rgb, uint32_t width, uint32_t height, int to_srgb) {
+    if (!path || !rgb || width == 0 || height == 0) {
+        set_error("pt_host_save_png: bad argument");
+        return PT_ERR_INVALID;
+    }
+    try {
+        save_png(path, rgb, width, height, to_srgb != 0);
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return PT_ERR_INVALID;
+    }
+    return PT_OK;
+}
+
+int pt_host_load_image(const char* path, float** rgb, uint32_t* width, uint32_t* height) {
+    if (!path || !rgb || !width || !height) {
+        set_error("pt_host_load_image: null argument");
+        return PT_ERR_INVALID;
+    }
+    try {
+        std::vector<float> px;
+        if (!load_image_linear(path, px, *width, *height)) {
+            set_error(std::string("Fail to load image file: \"") + path + "\"! (PNG, binary PPM and PFM are decoded here)");
+            return PT_ERR_INVALID;
+        }
+        *rgb = static_cast<float*>(std::malloc(px.size() * sizeof(float)));
+        if (!*rgb) {
+            set_error("pt_host_load_image: out of memory");
+            return PT_ERR_DEVICE;
+        }
+        std::memcpy(*rgb, px.data(), px.size() * sizeof(float));
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return PT_ERR_INVALID;
+    }
+    return PT_OK;
+}
 
 }  // extern "C"

@@ -40,42 +40,13 @@ std::string folder_of(const std::string& path) {
     return p == std::string::npos ? std::string() : path.substr(0, p + 1);
 }
 
-// sRGB -> linear (include/pt/color.h:70-83)
-float to_linear(float v) { return v <= 0.04045f ? v * (1.0f / 12.92f) : std::pow((v + 0.055f) * (1.0f / 1.055f), 2.4f); }
-
 bool load_texture(const std::string& path, pt_host_scene& s, int32_t& id) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return false;
-    std::string magic;
-    f >> magic;
-    int w = 0, h = 0;
     std::vector<float> rgb;
-    if (magic == "P6") {
-        int maxv = 0;
-        f >> w >> h >> maxv;
-        f.get();
-        if (w <= 0 || h <= 0 || maxv != 255) return false;
-        std::vector<unsigned char> raw(size_t(w) * h * 3);
-        f.read(reinterpret_cast<char*>(raw.data()), std::streamsize(raw.size()));
-        rgb.resize(raw.size());
-        for (size_t i = 0; i < raw.size(); ++i) rgb[i] = to_linear(float(raw[i]) / 255.f);  // src/bitmap.cpp:79-90
-    } else if (magic == "PF") {
-        float scale = 0;
-        f >> w >> h >> scale;
-        f.get();
-        if (w <= 0 || h <= 0 || scale >= 0) return false;  // little-endian only
-        rgb.resize(size_t(w) * h * 3);
-        std::vector<float> row(size_t(w) * 3);
-        for (int y = h - 1; y >= 0; --y) {  // PFM stores bottom row first
-            f.read(reinterpret_cast<char*>(row.data()), std::streamsize(row.size() * sizeof(float)));
-            std::memcpy(&rgb[size_t(y) * w * 3], row.data(), row.size() * sizeof(float));
-        }
-    } else {
-        return false;
-    }
+    uint32_t w = 0, h = 0;
+    if (!pt_host::load_image_linear(path, rgb, w, h)) return false;  // PNG, PPM, PFM (src/bitmap.cpp:68-93)
     id = int32_t(s.textures.size());
     s.tex_data.push_back(std::move(rgb));
-    s.textures.push_back(pt_texture{uint32_t(w), uint32_t(h), nullptr});
+    s.textures.push_back(pt_texture{w, h, nullptr});
     return true;
 }
 
@@ -105,12 +76,12 @@ void load_mtl(const std::string& path, pt_host_scene& s) {
             std::string tex, tok;
             while (is >> tok) tex = tok;
             int32_t id = -1;
-            // the reference's scenes name JPG / PNG files; tools/convert_textures.py writes <stem>.ppm next to them
+            // PNG files are decoded here; for the reference's JPG files tools/convert_textures.py writes <stem>.ppm next to them
             const std::string full = folder_of(path) + tex;
             const size_t dot = full.find_last_of('.');
             const std::string stem = dot == std::string::npos ? full : full.substr(0, dot);
-            if (!load_texture(full, s, id) && !load_texture(stem + ".ppm", s, id) && !load_texture(stem + ".pfm", s, id))
-                throw std::runtime_error("Fail to load image file: \"" + full + "\"! (binary PPM/PFM textures only; see tools/convert_textures.py)");
+            if (!load_texture(full, s, id) && !load_texture(stem + ".ppm", s, id) && !load_texture(stem + ".png", s, id) && !load_texture(stem + ".pfm", s, id))
+                throw std::runtime_error("Fail to load image file: \"" + full + "\"! (PNG, PPM and PFM are decoded here; convert JPEG files with tools/convert_textures.py)");
             s.mats[cur].tex = id;
         }
     }

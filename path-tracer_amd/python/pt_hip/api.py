@@ -102,6 +102,8 @@ def host_lib():
         L.pt_host_scene_desc.restype = C.POINTER(SceneDesc)
         L.pt_host_scene_desc.argtypes = [C.c_void_p]
         L.pt_host_scene_free.argtypes = [C.c_void_p]
+        L.pt_host_save_png.argtypes = [C.c_char_p, c_f32p, C.c_uint32, C.c_uint32, C.c_int]
+        L.pt_host_load_image.argtypes = [C.c_char_p, C.POINTER(c_f32p), c_u32p, c_u32p]
         _host = L
     return _host
 
@@ -205,6 +207,22 @@ def build_bvh_gpu(verts, vi, device=0):
     L.pt_hip_free(nodes_p)
     L.pt_hip_free(ids_p)
     return nodes, ids, depth.value
+
+
+def save_png(path, rgb, to_srgb=True):
+    """Bitmap::savePNG through pt_host_save_png: rgb is height x width x 3 float32 (linear when to_srgb)."""
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    _chk_host(host_lib().pt_host_save_png(str(path).encode(), _p(rgb, c_f32p), rgb.shape[1], rgb.shape[0], 1 if to_srgb else 0))
+
+
+def load_image(path):
+    """Bitmap::load through pt_host_load_image (PNG, PPM, PFM): height x width x 3 float32, linear."""
+    L = host_lib()
+    ptr, w, h = c_f32p(), C.c_uint32(), C.c_uint32()
+    _chk_host(L.pt_host_load_image(str(path).encode(), C.byref(ptr), C.byref(w), C.byref(h)))
+    out = np.ctypeslib.as_array(ptr, shape=(h.value, w.value, 3)).copy()
+    L.pt_host_free(ptr)
+    return out
 
 
 def make_camera(sd):

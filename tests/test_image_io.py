@@ -1,0 +1,133 @@
+"""PNG output and texture input of the host library (pt_host_save_png / pt_host_load_image) against PIL, and the front end's
+progressive accumulation.  The reference writes PNG through stb_image_write and reads textures through stb_image
+(src/bitmap.cpp:68-93, 122-144); pixel values of a PNG do not depend on the codec, so PIL is the checker here."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from pt_hip import api
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+REF_TEX = "/root/reference/scenes/bathroom/textures"
+
+
+def _to_linear(u8):
+    v = u8.astype(np.float32) / np.float32(255.0)
+    return np.where(v <= 0.04045, v * np.float32(1.0 / 12.92), np.power((v + np.float32(0.055)) * np.float32(1.0 / 1.055), np.float32(2.4))).astype(np.float32)
+
+
+def test_written_png_is_what_savePNG_would_store(tmp_path):
+    rng = np.random.default_rng(3)
+    img = rng.uniform(-0.2, 1.4, (37, 53, 3)).astype(np.float32)   # values outside [0, 1] are clamped
+    for srgb in (True, False):
+        path = tmp_path / ("a%d.png" % srgb)
+        api.save_png(path, img, to_srgb=srgb)
+        got = np.asarray(Image.open(path).convert("RGB"))
+        v = img
+        if srgb:   # Color3f::toSRGB (include/pt/color.h:57-69) in float32, as the reference evaluates it
+            v = np.where(img <= np.float32(0.0031308), np.float32(12.92) * img,
+                         np.float32(1.055) * np.power(np.maximum(img, 0), np.float32(1.0 / 2.4)) - np.float32(0.055)).astype(np.float32)
+        want = np.clip(np.float32(255.0) * v, 0.0, 255.0).astype(np.uint8)   # truncation, src/bitmap.cpp:127-131
+        assert got.shape == want.shape
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1     # powf of the C library vs numpy's: last-bit cases at a step
+        assert (got == want).mean() > 0.999
+    big = rng.uniform(0, 1, (300, 411, 3)).astype(np.float32)          # several stored blocks (> 65535 bytes)
+    api.save_png(tmp_path / "big.png", big, to_srgb=False)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "big.png")), np.clip(255.0 * big, 0, 255).astype(np.uint8))
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "LA", "P", "1", "I;16"])
+def test_png_files_of_every_colour_type_decode_as_pil_decodes_them(tmp_path, mode):
+    rng = np.random.default_rng(11)
+    h, w = 45, 67
+    smooth = (np.add.outer(np.arange(h), np.arange(w)) * 3 % 256).astype(np.uint8)   # compressible: dynamic Huffman codes, every filter
+    noise = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgba = np.where(rng.random((h, w, 1)) < 0.5, noise, smooth[..., None])
+    if mode == "I;16":
+        im = Image.fromarray((rgba[..., 0].astype(np.uint16) << 8) | rgba[..., 1])
+    elif mode in ("P", "1"):
+        im = Image.fromarray(rgba[..., :3]).convert(mode)
+    else:
+        im = Image.fromarray(rgba).convert(mode)
+    path = tmp_path / "t.png"
+    im.save(path, optimize=True)
+    got = api.load_image(path)
+    if mode == "I;16":
+        want8 = np.repeat((np.asarray(im) >> 8).astype(np.uint8)[..., None], 3, -1)
+    else:
+        want8 = np.asarray(Image.open(path).convert("RGB"))
+    assert got.shape == (h, w, 3)
+    assert np.allclose(got, _to_linear(want8), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TEX), reason="reference tree not present")
+def test_the_references_own_png_textures_decode_as_pil_decodes_them():
+    for name in ("floor_tiles.png", "rug_mask.png"):
+        got = api.load_image(os.path.join(REF_TEX, name))
+        want8 = np.asarray(Image.open(os.path.join(REF_TEX, name)).convert("RGB"))
+        assert got.shape == want8.shape
+        assert np.allclose(got, _to_linear(want8), rtol=2e-6, atol=1e-7)
+
+
+def test_jpeg_and_garbage_are_refused_with_a_message(tmp_path):
+    p = tmp_path / "x.jpg"
+    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(p)
+    with pytest.raises(api.PtError, match="Fail to load image file"):
+        api.load_image(p)
+    q = tmp_path / "bad.png"
+    q.write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
+    with pytest.raises(api.PtError):
+        api.load_image(q)
+
+
+def _write_scene(folder, name="cornell-box"):
+    """A small OBJ/MTL/XML scene in the reference's file formats with a PNG texture on the floor."""
+    d = folder / name
+    (d / "textures").mkdir(parents=True)
+    tex = (np.indices((16, 16)).sum(0) % 2 * 200 + 30).astype(np.uint8)
+    Image.fromarray(np.stack([tex, 255 - tex, tex // 2], -1)).save(d / "textures" / "checker.png")
+    (d / (name + ".mtl")).write_text(
+        "newmtl floor\nKd 0.7 0.7 0.7\nKs 0 0 0\nNs 1\nmap_Kd textures/checker.png\n"
+        "newmtl wall\nKd 0.6 0.2 0.2\nKs 0.1 0.1 0.1\nNs 20\nnewmtl lamp\nKd 0 0 0\nKs 0 0 0\nNs 1\n")
+    (d / (name + ".obj")).write_text(
+        "mtllib %s.mtl\nv -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nv -1 2 -1\nv 1 2 -1\nv -0.3 1.9 -0.3\nv 0.3 1.9 -0.3\nv 0.3 1.9 0.3\nv -0.3 1.9 0.3\n"
+        "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+        "usemtl floor\nf 1/1 3/3 2/2\nf 1/1 4/4 3/3\nusemtl wall\nf 1 2 6\nf 1 6 5\nusemtl lamp\nf 7 8 9\nf 7 9 10\n" % name)
+    (d / (name + ".xml")).write_text(
+        '<?xml version="1.0" encoding="utf-8"?>\n<camera type="perspective" width="64" height="48" fovy="50">\n'
+        '<eye x="0" y="1" z="3.5"/>\n<lookat x="0" y="0.8" z="0"/>\n<up x="0" y="1" z="0"/>\n</camera>\n<light mtlname="lamp" radiance="20,20,20"/>\n')
+    return d
+
+
+@pytest.mark.gpu
+def test_progressive_batches_add_up_to_the_one_shot_image_and_png_is_written(tmp_path):
+    """PathTracer --progressive N renders the frame in batches of N samples and rewrites result.png after each; the final
+    image must be the one-shot image (same sample numbers, sums in another order), and the PNG the 8-bit sRGB form of the EXR."""
+    from exr_lite import read_rgb as read_exr
+    exe = os.path.join(ROOT, "path-tracer_amd", "bin", "PathTracer")
+    _write_scene(tmp_path / "scenes")
+    outs = {}
+    for tag, extra in (("one", []), ("prog", ["--progressive", "5"])):
+        out = tmp_path / tag
+        out.mkdir()
+        r = subprocess.run([exe, "--no-gui", "-s", "16", "--scenes", str(tmp_path / "scenes"), "--out", str(out), "cornell-box"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        if extra:
+            assert "[5/16 spp]" in r.stdout and "[15/16 spp]" in r.stdout
+        outs[tag] = {k: read_exr(str(out / (k + ".exr"))) for k in ("albedo", "normal", "result")}
+        for k in ("albedo", "normal", "result"):
+            png = np.asarray(Image.open(out / (k + ".png")).convert("RGB")).astype(int)
+            lin = outs[tag][k]
+            v = lin if k == "normal" else np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(np.maximum(lin, 0), 1 / 2.4) - 0.055)
+            assert np.abs(png - np.clip(255.0 * v, 0, 255).astype(int)).max() <= 1
+    assert outs["one"]["result"].mean() > 0.01
+    # (the same pass twice: neighbouring film regions add their borders with float atomics, in an order that varies)
+    assert np.allclose(outs["one"]["albedo"], outs["prog"]["albedo"], rtol=2e-6, atol=1e-7)
+    assert np.allclose(outs["one"]["result"], outs["prog"]["result"], rtol=2e-5, atol=1e-6)
+    # the texture reached the device: the floor's albedo shows both checker colours
+    alb = outs["one"]["albedo"][40]
+    assert alb[:, 0].max() - alb[:, 0].min() > 0.3
