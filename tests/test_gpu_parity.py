@@ -777,15 +777,20 @@ def test_full_size_bathroom_workload_properties():
 
 def test_fifty_million_triangle_ultra_hd_workload_properties():
     """The largest configuration in shape: the library stand-in tessellated to 49 M triangles (a 98 M-node tree, 34 levels)
-    at 3840x2160 (the sampler's 4096-wide grid).  The tree is built once, by the host builder; the oracle traverses the same
-    tree (its own single-threaded builder would take minutes here; that both builders produce the same tree is checked on
-    smaller scenes in test_host.py).  Checked: both traversal orders agree bit for bit on a million random rays and on
+    at 3840x2160 (the sampler's 4096-wide grid).  The tree is built by the GPU builder (api.Scene's default) and, once more,
+    by the host builder: the two must be identical node for node at this size too.  The oracle traverses the same tree (its
+    own single-threaded builder would take minutes here; that it produces the host builder's tree is checked on smaller
+    scenes in test_host.py).  Checked: both traversal orders agree bit for bit on a million random rays and on
     their occlusion flags, every 97th of them equals the oracle's answer, per-sample radiance agrees with the oracle, films
     of disjoint sample ranges add up, and both modes trace the same paths."""
     sd = synth.library_synth(detail=44, width=3840, height=2160)
     assert sd.n_tris > 49_000_000
     g = api.Scene(sd)
     assert g.host.depth >= 30
+    host_nodes, host_ids, host_depth = api.build_bvh(sd.verts, sd.vi)
+    assert host_depth == g.host.depth and np.array_equal(host_ids, g.host.prim_ids)
+    assert np.array_equal(host_nodes.view(np.uint32), g.host.nodes.view(np.uint32))
+    del host_nodes, host_ids
     o = orc.Scene(sd, bvh=(g.host.nodes, g.host.prim_ids))
     rng = np.random.default_rng(44)
     n = 1 << 20

@@ -6,7 +6,7 @@ import glob, json, os, re, shutil, subprocess, sys
 tag, new, old = sys.argv[1:4]
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-pairs = [("%s_bench_%s.json" % (tag, k), "r3_%s_bench_%s.json" % (new, k)) for k in ("library_fast", "veach_fast", "veach_exact", "library_exact")]
+pairs = [("%s_bench_%s.json" % (tag, k), "r3_%s_bench_%s.json" % (new, k)) for k in ("library_fast", "veach_fast", "veach_exact", "library_exact", "cornell64spp_fast", "bathroom2048spp_fast")]
 pairs += [("%s_prof_bench_library_fast.txt" % tag, "r3_%s_rocprof_bench_library_fast.txt" % new),
           ("%s_prof_library_fast.txt" % tag, "r3_%s_rocprof_pmc_library512spp_fast.txt" % new),
           ("%s_prof_veach_fast.txt" % tag, "r3_%s_rocprof_pmc_veach512spp_fast.txt" % new)]
