@@ -42,8 +42,10 @@ void pt_host_filter_table(float* out33);
  * through Color3f::toSRGB (include/pt/color.h:57-69) first, then * 255, clamped, truncated to 8 bits. */
 int pt_host_save_png(const char* path, const float* rgb, uint32_t width, uint32_t height, int to_srgb);
 /* Bitmap::load (src/bitmap.cpp:68-93) for PNG (non-interlaced; grey, palette, RGB, with or without alpha, 1-16 bits),
- * binary PPM and PFM: 8-bit samples / 255 through Color3f::toLinearRGB (include/pt/color.h:70-83).  *rgb receives
- * width x height x 3 floats (malloc'd; release with pt_host_free).  JPEG files are not decoded (PT_ERR_INVALID). */
+ * JPEG (8-bit baseline and progressive Huffman-coded files, grey or YCbCr), binary PPM and PFM: 8-bit samples / 255
+ * through Color3f::toLinearRGB (include/pt/color.h:70-83).  *rgb receives width x height x 3 floats (malloc'd; release with
+ * pt_host_free).  JPEG decoders differ in how they round: values agree with stb_image's (which the reference uses) and
+ * libjpeg's to within a level or two of the 8-bit scale, not bit for bit. */
 int pt_host_load_image(const char* path, float** rgb, uint32_t* width, uint32_t* height);
 
 /* ---- scene files --------------------------------------------------------------------------------------------------- */
@@ -51,8 +53,8 @@ int pt_host_load_image(const char* path, float** rgb, uint32_t* width, uint32_t*
 typedef struct pt_host_scene pt_host_scene;
 
 /* Scene::loadOBJ + Scene::loadXML + Scene::preprocess (src/scene.cpp:23-177, 222-263) for ./<dir>/<name>.obj|.xml:
- * reads mesh, materials (textures: PNG, PPM and PFM; for a JPEG file a converted <stem>.ppm / .png next to it is taken,
- * see tools/convert_textures.py, anything else is reported as an error), camera and lights, builds
+ * reads mesh, materials (textures: PNG, JPEG, PPM and PFM as pt_host_load_image decodes them; anything else is reported
+ * as an error), camera and lights, builds
  * the BVH and the light table.  The returned description stays valid until pt_host_scene_free. */
 int pt_host_scene_load(const char* obj_path, const char* xml_path, pt_host_scene** out);
 const pt_scene_desc* pt_host_scene_desc(const pt_host_scene* s);

@@ -109,7 +109,7 @@ int pt_host_load_image(const char* path, float** rgb, uint32_t* width, uint32_t*
     try {
         std::vector<float> px;
         if (!load_image_linear(path, px, *width, *height)) {
-            set_error(std::string("Fail to load image file: \"") + path + "\"! (PNG, binary PPM and PFM are decoded here)");
+            set_error(std::string("Fail to load image file: \"") + path + "\"! (PNG, JPEG, binary PPM and PFM are decoded here)");
             return PT_ERR_INVALID;
         }
         *rgb = static_cast<float*>(std::malloc(px.size() * sizeof(float)));

@@ -1,8 +1,8 @@
 // Image files of the host front end without third-party codecs: PNG output as the reference writes it
-// (Bitmap::savePNG, src/bitmap.cpp:122-144: sRGB, 8 bits, three channels) and PNG / PPM / PFM input for textures
+// (Bitmap::savePNG, src/bitmap.cpp:122-144: sRGB, 8 bits, three channels) and PNG / JPEG / PPM / PFM input for textures
 // (Bitmap::load, src/bitmap.cpp:68-93: 8-bit values / 255, sRGB -> linear).  The PNG writer stores the image in
 // uncompressed deflate blocks; the reader carries its own inflate (fixed and dynamic Huffman codes) and undoes the five
-// scanline filters.  Baseline and progressive JPEG are not decoded here.
+// scanline filters.  JPEG files go through jpeg_decode.cpp.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -342,7 +342,7 @@ bool read_png_rgb8(const std::string& path, std::vector<uint8_t>& rgb, uint32_t&
 // Returns false when the file does not exist or is of another format.
 bool load_image_linear(const std::string& path, std::vector<float>& rgb, uint32_t& w, uint32_t& h) {
     std::vector<uint8_t> px;
-    if (read_png_rgb8(path, px, w, h)) {
+    if (read_png_rgb8(path, px, w, h) || read_jpeg_rgb8(read_file(path), px, w, h)) {
         rgb.resize(px.size());
         for (size_t i = 0; i < px.size(); ++i) rgb[i] = to_linear(float(px[i]) / 255.f);  // src/bitmap.cpp:79-90
         return true;

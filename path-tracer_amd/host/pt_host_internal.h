@@ -24,6 +24,7 @@ void set_error(const std::string& msg);
 // image_io.cpp -- these throw std::runtime_error on malformed files
 void save_png(const std::string& path, const float* rgb, uint32_t w, uint32_t h, bool srgb);
 bool read_png_rgb8(const std::string& path, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h);
+bool read_jpeg_rgb8(const std::vector<uint8_t>& file, std::vector<uint8_t>& rgb, uint32_t& w, uint32_t& h);  // jpeg_decode.cpp
 bool load_image_linear(const std::string& path, std::vector<float>& rgb, uint32_t& w, uint32_t& h);
 
 }  // namespace pt_host

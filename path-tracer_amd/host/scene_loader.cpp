@@ -43,7 +43,7 @@ std::string folder_of(const std::string& path) {
 bool load_texture(const std::string& path, pt_host_scene& s, int32_t& id) {
     std::vector<float> rgb;
     uint32_t w = 0, h = 0;
-    if (!pt_host::load_image_linear(path, rgb, w, h)) return false;  // PNG, PPM, PFM (src/bitmap.cpp:68-93)
+    if (!pt_host::load_image_linear(path, rgb, w, h)) return false;  // PNG, JPEG, PPM, PFM (src/bitmap.cpp:68-93)
     id = int32_t(s.textures.size());
     s.tex_data.push_back(std::move(rgb));
     s.textures.push_back(pt_texture{w, h, nullptr});
@@ -76,12 +76,12 @@ void load_mtl(const std::string& path, pt_host_scene& s) {
             std::string tex, tok;
             while (is >> tok) tex = tok;
             int32_t id = -1;
-            // PNG files are decoded here; for the reference's JPG files tools/convert_textures.py writes <stem>.ppm next to them
+            // PNG and JPEG files are decoded here; a converted <stem>.ppm / .png / .pfm next to an unreadable file is taken instead
             const std::string full = folder_of(path) + tex;
             const size_t dot = full.find_last_of('.');
             const std::string stem = dot == std::string::npos ? full : full.substr(0, dot);
             if (!load_texture(full, s, id) && !load_texture(stem + ".ppm", s, id) && !load_texture(stem + ".png", s, id) && !load_texture(stem + ".pfm", s, id))
-                throw std::runtime_error("Fail to load image file: \"" + full + "\"! (PNG, PPM and PFM are decoded here; convert JPEG files with tools/convert_textures.py)");
+                throw std::runtime_error("Fail to load image file: \"" + full + "\"! (PNG, JPEG, PPM and PFM are decoded here)");
             s.mats[cur].tex = id;
         }
     }

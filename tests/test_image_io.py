@@ -72,8 +72,65 @@ def test_the_references_own_png_textures_decode_as_pil_decodes_them():
         assert np.allclose(got, _to_linear(want8), rtol=2e-6, atol=1e-7)
 
 
-def test_jpeg_and_garbage_are_refused_with_a_message(tmp_path):
-    p = tmp_path / "x.jpg"
+def _to_srgb8(lin):
+    s = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * np.power(np.maximum(lin, 0), 1 / 2.4) - 0.055)
+    return np.rint(s * 255).astype(int)
+
+
+def _jpeg_matches_pil(path):
+    """Decoders round the inverse DCT and the colour conversion differently (stb_image, which the reference uses, and
+    libjpeg, which PIL uses, do not agree bit for bit either): within 3 of 255 everywhere, 0.25 on average."""
+    got = _to_srgb8(api.load_image(path))
+    want = np.asarray(Image.open(path).convert("RGB")).astype(int)
+    assert got.shape == want.shape
+    d = np.abs(got - want)
+    assert d.max() <= 3 and d.mean() < 0.25 and (d > 2).mean() < 2e-3, (d.max(), d.mean())
+
+
+@pytest.mark.parametrize("progressive", [False, True])
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+@pytest.mark.parametrize("size", [(123, 211), (16, 16), (9, 31)])
+def test_jpeg_files_decode_as_pil_decodes_them(tmp_path, progressive, subsampling, size):
+    rng = np.random.default_rng(1)
+    h, w = size
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([np.sin(xx / 9.0) * 100 + 128, np.cos(yy / 7.0) * 90 + 120, (xx + yy) % 64 * 4], -1)
+    img[h // 3:h // 2, w // 4:w // 2] = [255, 0, 0]      # sharp chroma edges: the up-sampling filter matters there
+    img[h // 2:, w // 2:3 * w // 4] = [0, 0, 255]
+    img = (img + rng.integers(-12, 12, img.shape)).clip(0, 255).astype(np.uint8)
+    for quality in (95, 40):
+        p = tmp_path / ("c%d.jpg" % quality)
+        Image.fromarray(img).save(p, quality=quality, subsampling=subsampling, progressive=progressive, optimize=progressive)
+        _jpeg_matches_pil(p)
+    g = tmp_path / "grey.jpg"
+    Image.fromarray(img[..., 0]).save(g, quality=80, progressive=progressive)
+    _jpeg_matches_pil(g)
+
+
+def test_jpeg_with_restart_intervals(tmp_path):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (70, 90, 3), dtype=np.uint8)
+    p = tmp_path / "r.jpg"
+    try:
+        Image.fromarray(img).save(p, quality=85, subsampling=2, restart_marker_blocks=3)
+    except TypeError:
+        pytest.skip("this PIL cannot write restart markers")
+    if b"\xff\xdd" not in p.read_bytes():
+        pytest.skip("this PIL ignores restart_marker_blocks")
+    _jpeg_matches_pil(p)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TEX), reason="reference tree not present")
+def test_the_references_own_jpeg_textures_decode_as_pil_decodes_them():
+    """Seven files, four of them progressive, 4:2:0 and 4:4:4."""
+    names = sorted(n for n in os.listdir(REF_TEX) if n.endswith(".jpg"))
+    assert len(names) == 7
+    for name in names:
+        _jpeg_matches_pil(os.path.join(REF_TEX, name))
+
+
+def test_garbage_is_refused_with_a_message(tmp_path):
+    p = tmp_path / "x.bmp"
     Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(p)
     with pytest.raises(api.PtError, match="Fail to load image file"):
         api.load_image(p)
@@ -81,6 +138,12 @@ def test_jpeg_and_garbage_are_refused_with_a_message(tmp_path):
     q.write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
     with pytest.raises(api.PtError):
         api.load_image(q)
+    j = tmp_path / "bad.jpg"
+    j.write_bytes(b"\xff\xd8\xff\xc0\x00\x0b\x08\x00\x10\x00\x10\x04")   # four components: refused, not mis-decoded
+    with pytest.raises(api.PtError, match="JPEG"):
+        api.load_image(j)
+    with pytest.raises(api.PtError):
+        api.load_image(tmp_path / "missing.png")
 
 
 def _write_scene(folder, name="cornell-box"):
