@@ -119,6 +119,14 @@ def gather_peak():
     return GATHER_PEAK_FALLBACK, "fallback constant"
 
 
+def counters_ok(c):
+    return bool(c) and c.get("bytes_per_launch") and c.get("avg_launch_ms")
+
+
+def traffic_of(c):
+    return c["bytes_per_launch"]
+
+
 def host_cores():
     """(threads the CPU baseline uses, cores this process may run on, cores of the machine).  The GPU box gives a one-GPU
     job a share of a much larger host, and says so through OMP_NUM_THREADS."""
@@ -252,7 +260,7 @@ def main():
         cst = scene.render_device(film.data_ptr(), s0, min(s1, s0 + pass_spp), traversal=mode, flags=api.FLAG_COUNT_WORK, block=share)
         units = {"generate": sum(s["paths"] for s in stats), "film": sum(s["paths"] for s in stats),
                  "extend": sum(s["closest_rays"] - s["paths"] for s in stats), "shadow": sum(s["any_rays"] for s in stats),
-                 "shade": sum(s["closest_rays"] for s in stats)}   # upper bound: misses leave the queue before shading
+                 "shade": sum(s["shaded_hits"] for s in stats)}    # misses leave the queue before shading
         cunits = {"generate": cst["paths"], "extend": cst["closest_rays"] - cst["paths"], "shadow": cst["any_rays"]}
         per_unit = dict(UNIT_BYTES)
         lane_acc = dict(LANE_ACCESSES)
@@ -264,11 +272,6 @@ def main():
             bvh[k] = {"nodes_per_ray": n_node, "of_them_from_lds": n_lds, "tris_per_ray": n_tri}
             per_unit[k] += NODE_BYTES[a.traversal] * n_node + TRI_BYTES * n_tri
             lane_acc[k] += NODE_LOADS[a.traversal] * (n_node - n_lds) + TRI_LOADS * n_tri
-        seconds = kms[dominant] * 1e-3
-        achieved_hbm = units[dominant] * per_unit[dominant] / seconds / 1e9 if seconds > 0 else 0.0
-        achieved_gather = units[dominant] * lane_acc[dominant] / seconds / 1e9 if seconds > 0 else 0.0   # G lane accesses per second
-        peak_cu, peak_src = gather_peak()
-        peak_gather = peak_cu * N_CUS / 1e9
         # Hardware counters cannot be read from inside this process: the counter figures of the dominant kernel come from the
         # committed rocprofv3 --pmc passes of the same workload and pass size (profiles/traffic.json), stamped with the digest
         # of the device sources they were measured on; a different digest marks them stale.
@@ -280,6 +283,16 @@ def main():
                 stale = t.get("kernel_source_hash") != kernel_source_hash()
         except (OSError, ValueError, KeyError):
             pass
+        seconds = kms[dominant] * 1e-3
+        achieved_hbm = units[dominant] * per_unit[dominant] / seconds / 1e9 if seconds > 0 else 0.0
+        achieved_gather = units[dominant] * lane_acc[dominant] / seconds / 1e9 if seconds > 0 else 0.0   # G lane accesses per second
+        peak_cu, peak_src = gather_peak()
+        peak_gather = peak_cu * N_CUS / 1e9
+        # The traversal kernels are priced against the gather rate.  k_shade streams its queues (coalesced) and gathers one
+        # 128-byte record per hit: its lane accesses are mostly of the cheap, coalesced kind, and what it moves is priced
+        # against HBM instead.
+        gather_bound = dominant in ("generate", "extend", "shadow")
+        hbm_measured = (traffic_of(counters) / counters["avg_launch_ms"] / 1e-3 / 1e9) if counters_ok(counters) else None   # GB/s that crossed the fabric
         launch_s = kms[dominant] / max(kn[dominant], 1) * 1e-3
         traffic = counters.get("bytes_per_launch")
         valu, lanes = counters.get("valu_issue_frac"), counters.get("lanes_per_valu_inst_frac")
@@ -307,11 +320,21 @@ def main():
             # could take.  achieved = 16-byte lane accesses the kernel's queries need (counted by an instrumented pass) per
             # second of kernel time; peak = the measured rate of a chain of dependent 64-byte gathers from an L2-resident table
             # x 256 CUs; frac = achieved / peak.  The contract's HBM view of the same kernel is under "hbm".
-            "roofline": {"bound": "l1-gather", "bound_note": "per-lane gathers of different addresses: the CU's address/data path takes one lane x 16 B per clock "
-                                                             "(tools/gather_roof.hip); HBM, L2 and VALU roofs are not near",
+            "roofline": {"bound": "l1-gather" if gather_bound else "hbm",
+                         "bound_note": ("per-lane gathers of different addresses: the CU's address/data path takes one lane x 16 B per clock "
+                                        "(tools/gather_roof.hip); HBM, L2 and VALU roofs are not near") if gather_bound else
+                                       ("queues streamed once per bounce plus one gathered 128-byte record per hit; algorithmic bytes count what "
+                                        "the caches serve too, the measured share of the HBM peak is hbm.measured_frac"),
                          "kernel": "k_" + dominant,
-                         "achieved": achieved_gather, "peak": peak_gather, "unit": "G lane-accesses/s (16 B each)", "frac": achieved_gather / peak_gather,
-                         "peak_source": peak_src, "lane_accesses_per_unit": lane_acc[dominant],
+                         "achieved": achieved_gather if gather_bound else (hbm_measured if hbm_measured is not None else achieved_hbm),
+                         "achieved_is": "counted lane accesses / kernel time" if gather_bound else
+                                        ("measured fabric bytes / kernel time (committed counter pass)" if hbm_measured is not None else "algorithmic bytes / kernel time"),
+                         "peak": peak_gather if gather_bound else HBM_PEAK_GBS,
+                         "unit": "G lane-accesses/s (16 B each)" if gather_bound else "GB/s",
+                         "frac": achieved_gather / peak_gather if gather_bound else (hbm_measured if hbm_measured is not None else achieved_hbm) / HBM_PEAK_GBS,
+                         "gather": {"achieved": achieved_gather, "peak": peak_gather, "unit": "G lane-accesses/s (16 B each)", "frac": achieved_gather / peak_gather,
+                                    "peak_source": peak_src, "lane_accesses_per_unit": lane_acc[dominant],
+                                    "note": "every access counted as a gather; coalesced queue accesses cost a quarter of that"},
                          "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (fabric requests x 64 B)",
                          "hbm": {"achieved": achieved_hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_hbm / HBM_PEAK_GBS,
                                  "note": "algorithmic bytes per unit x units / kernel time: counts gathers that L2 serves, so it may exceed the peak",

@@ -181,6 +181,8 @@ typedef struct pt_stats {
     uint64_t nodes_from_lds[3];
     uint32_t samples_per_pass; /* samples of every pixel kept in flight per pass (the automatic choice when the caller gave 0) */
     uint32_t passes;           /* passes the call took */
+    uint64_t shaded_hits;      /* hit-list entries handed to the shade step (closest-hit queries that found something); the
+                                * further iterations that a tail launch runs on its own are not listed */
 } pt_stats;
 /* indices into kernel_ms / kernel_launches; PT_K_FINISH = the launches that run few paths for many iterations in one go
  * (the thinned-out tail of a pass; the last chains of specular bounces beyond max_bounce iterations);

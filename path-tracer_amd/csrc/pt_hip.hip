@@ -633,33 +633,45 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             o[4] = make_float4(n[7], n[8], 0.0f, 0.0f);
         };
         if (d->n_tris > kPrimMask) return fail(PT_ERR_LIMIT, "more than 2^29-1 triangles");
+        bool any_normals = false;
+        for (uint32_t t = 0; t < d->n_tris && !any_normals; ++t) any_normals = has_normals(t);
         if (int rc = fill_upload<float4>(
                 s, d->n_tris, [](size_t u) { return size_t(kTriRecVec4) * u; }, &dev.trec, [&](size_t ti_, float4* o) {
                     const uint32_t t = uint32_t(ti_);
                     const float *a = vert(t, 0), *b = vert(t, 1), *c = vert(t, 2);
-                    float n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    if (has_normals(t))
-                        for (int k = 0; k < 3; ++k) std::memcpy(n + 3 * k, normal(t, k), 12);
                     uint32_t flags = has_normals(t) ? kTriHasNormals : 0u;
                     if (d->n_uvs != 0 && d->ti && d->ti[3 * size_t(t)] != 0) flags |= kTriHasUvs;
                     const int32_t lid = d->light_id[t];
-                    const pt_material& m = d->mats[d->mat_id[t]];
-                    float lemit[3] = {0.0f, 0.0f, 0.0f}, inv_area = 0.0f;
-                    if (lid >= 0) {
-                        const pt_light& l = d->lights[lid];
-                        std::memcpy(lemit, l.lemit, 12);
-                        inv_area = float(1.0 / double(l.area));
-                    }
                     o[0] = make_float4(a[0], a[1], a[2], b[0]);
                     o[1] = make_float4(b[1], b[2], c[0], c[1]);
-                    o[2] = make_float4(c[2], bits(flags), bits(uint32_t(lid)), bits(uint32_t(m.tex)));
-                    o[3] = make_float4(m.kd[0], m.kd[1], m.kd[2], m.ns);
-                    o[4] = make_float4(m.ks[0], m.ks[1], m.ks[2], inv_area);
-                    o[5] = make_float4(n[0], n[1], n[2], n[3]);
-                    o[6] = make_float4(n[4], n[5], n[6], n[7]);
-                    o[7] = make_float4(lemit[0], lemit[1], lemit[2], n[8]);
+                    o[2] = make_float4(c[2], bits(flags), bits(uint32_t(lid)), bits(d->mat_id[t]));
+                    o[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (lid >= 0) {
+                        const pt_light& l = d->lights[lid];
+                        o[3] = make_float4(float(1.0 / double(l.area)), l.lemit[0], l.lemit[1], l.lemit[2]);
+                    }
                 }))
             return rc;
+        if (int rc = fill_upload<float4>(
+                s, any_normals ? d->n_tris : 1u, [](size_t u) { return size_t(kTriNormalVec4) * u; }, &dev.tnrm, [&](size_t ti_, float4* o) {
+                    const uint32_t t = uint32_t(ti_);
+                    float n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    if (any_normals && has_normals(t))
+                        for (int k = 0; k < 3; ++k) std::memcpy(n + 3 * k, normal(t, k), 12);
+                    o[0] = make_float4(n[0], n[1], n[2], n[3]);
+                    o[1] = make_float4(n[4], n[5], n[6], n[7]);
+                    o[2] = make_float4(n[8], 0.0f, 0.0f, 0.0f);
+                }))
+            return rc;
+        {
+            std::vector<float4> mats(size_t(kMaterialVec4) * std::max<uint32_t>(d->n_mats, 1u));
+            for (uint32_t i = 0; i < d->n_mats; ++i) {
+                const pt_material& m = d->mats[i];
+                mats[size_t(kMaterialVec4) * i] = make_float4(m.kd[0], m.kd[1], m.kd[2], m.ns);
+                mats[size_t(kMaterialVec4) * i + 1] = make_float4(m.ks[0], m.ks[1], m.ks[2], bits(uint32_t(m.tex)));
+            }
+            if (int rc = upload(s, mats.data(), mats.size(), &dev.mats)) return rc;
+        }
         std::vector<float4> lrec(size_t(kLightRecVec4) * d->n_lights);
         for (uint32_t i = 0; i < d->n_lights; ++i) {
             const pt_light& l = d->lights[i];
@@ -957,6 +969,8 @@ int run_bounces(pt_hip_scene* s, const PassArgs& pa, pt_stats* st, Timer& tm, bo
             if (st && !regrouped) {
                 st->any_rays += shadow.sum;
                 st->closest_rays += next.sum;
+                // the hit list this bounce's shade worked on (still in place: the extend that refills it runs later)
+                st->shaded_hits += fill_of(c + size_t(2 + int(consumed & 1u)) * K, K).sum;
             }
             regrouped = false;
             bound = std::min(bound, std::max(next.max, 1u));
@@ -1727,6 +1741,7 @@ int pt_hip_render_multi(pt_hip_scene* const* scenes, int n, const pt_render_para
                 st->nodes_fetched[j] += stats[k].nodes_fetched[j];
                 st->tris_fetched[j] += stats[k].tris_fetched[j];
                 st->nodes_from_lds[j] += stats[k].nodes_from_lds[j];
+                if (j == 0) st->shaded_hits += stats[k].shaded_hits;
             }
             for (int j = 0; j < PT_MAX_KERNEL_STATS; ++j) {
                 st->kernel_ms[j] += stats[k].kernel_ms[j];

@@ -27,17 +27,19 @@ static_assert(kFatLeafTris <= 15u, "the leaf reference has four bits for the tri
 // prefix of them from LDS.  kTreeletMax bounds what the scene builder orders that way.
 constexpr uint32_t kTreeletMax = 1024;
 
-// Shading record of one triangle: exactly one 128-byte line, 8 x float4, everything the shade step needs about the
-// surface it hit (the reference chases Triangle* -> TriangleMesh -> index arrays -> vertex arrays, and Material*,
-// AreaLight*: include/pt/shape.h:58-63, include/pt/mesh.h:31-55).  What every hit needs comes first, so that a hit on a
-// triangle without vertex normals that is no emitter reads five of the eight quarters:
-//   r0 {v0.x v0.y v0.z v1.x}  r1 {v1.y v1.z v2.x v2.y}  r2 {v2.z bits(flags) bits(light_id) bits(tex)}
-//   r3 {kd.r kd.g kd.b ns}  r4 {ks.r ks.g ks.b inv_area}
-//   r5 {n0.x n0.y n0.z n1.x}  r6 {n1.y n1.z n2.x n2.y}  r7 {lemit.r lemit.g lemit.b n2.z}
-// (lemit and inv_area are zero when the triangle is not an emitter, the normals when it has none).
+// Shading records of one triangle (the reference chases Triangle* -> TriangleMesh -> index arrays -> vertex arrays, and
+// Material*, AreaLight*: include/pt/shape.h:58-63, include/pt/mesh.h:31-55).  What every hit needs sits in ONE 64-byte
+// sector, so that a hit costs one sector of memory traffic however large the scene is:
+//   trec, 4 x float4:  r0 {v0.x v0.y v0.z v1.x}  r1 {v1.y v1.z v2.x v2.y}  r2 {v2.z bits(flags) bits(light_id) bits(material)}
+//                      r3 {inv_area lemit.r lemit.g lemit.b}   (read for emitters only; zero otherwise)
+//   tnrm, 3 x float4:  {n0.x n0.y n0.z n1.x} {n1.y n1.z n2.x n2.y} {n2.z 0 0 0}   (read for triangles with vertex normals)
+//   mats, 2 x float4 per MATERIAL: {kd.r kd.g kd.b ns} {ks.r ks.g ks.b bits(tex)} -- a table of a few hundred bytes that
+//                      stays in the nearest cache; its read depends on r2 and overlaps with the light record's
 constexpr uint32_t kTriHasNormals = 1u;  // mesh has normals and this face's first normal index is non-zero (mesh.h:37-39)
 constexpr uint32_t kTriHasUvs = 2u;      // same for texture coordinates (mesh.h:46-48)
-constexpr int kTriRecVec4 = 8;
+constexpr int kTriRecVec4 = 4;
+constexpr int kTriNormalVec4 = 3;
+constexpr int kMaterialVec4 = 2;
 // The primitive word of a leaf-array record (and of a hit-list entry) carries the triangle's index in its low bits and,
 // above them, which of the optional quarters of its shading record a hit on it needs -- known together with the hit, so
 // that the shade step can ask for exactly those in one round of loads.  Bit 31 stays clear: -1 means "no hit".
@@ -81,6 +83,8 @@ struct DevScene {
     const float4* tris;
     // ---- shading records (original triangle order) and light records (reference light order)
     const float4* trec;
+    const float4* tnrm;  // one record when no triangle has normals
+    const float4* mats;
     const float4* lrec;
     // ---- only for textured materials
     const float* uvs;

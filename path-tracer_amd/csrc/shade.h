@@ -10,38 +10,46 @@ namespace ptd {
 
 // ---------------------------------------------------------------------------------------------------- records
 
-// One triangle's shading record, loaded as independent 16-byte reads of one 128-byte line: five for every hit, the
-// quarters with the vertex normals and the emitted radiance only when the hit's primitive word asks for them.
+// What the shade step needs about the triangle it hit: the 64-byte record, the normals and the emitter quarter only when
+// the hit's primitive word asks for them, and the material's two quarters from the material table.
 struct TriRec {
     float4 r[kTriRecVec4];
+    float4 nr[kTriNormalVec4];
+    float4 m[kMaterialVec4];
     uint32_t index;  // the triangle's number (the primitive word without its flag bits)
     PTD void load(const DevScene& sc, uint32_t prim_word) {
         index = prim_word & kPrimMask;
         const float4* p = sc.trec + size_t(index) * kTriRecVec4;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) r[k] = p[k];
+        r[0] = p[0];
+        r[1] = p[1];
+        r[2] = p[2];
         const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        r[5] = r[6] = r[7] = zero;
+        r[3] = nr[0] = nr[1] = nr[2] = zero;
+        if (prim_word & kPrimEmitter) r[3] = p[3];
         if (prim_word & kPrimHasNormals) {
-            r[5] = p[5];
-            r[6] = p[6];
+            const float4* q = sc.tnrm + size_t(index) * kTriNormalVec4;
+            nr[0] = q[0];
+            nr[1] = q[1];
+            nr[2] = q[2];
         }
-        if (prim_word & (kPrimHasNormals | kPrimEmitter)) r[7] = p[7];
+        const float4* mt = sc.mats + size_t(as_u(r[2].w)) * kMaterialVec4;
+        m[0] = mt[0];
+        m[1] = mt[1];
     }
     PTD V3 v0() const { return V3{r[0].x, r[0].y, r[0].z}; }
     PTD V3 v1() const { return V3{r[0].w, r[1].x, r[1].y}; }
     PTD V3 v2() const { return V3{r[1].z, r[1].w, r[2].x}; }
     PTD uint32_t flags() const { return as_u(r[2].y); }
     PTD int32_t light_id() const { return int32_t(as_u(r[2].z)); }
-    PTD int32_t tex() const { return int32_t(as_u(r[2].w)); }
-    PTD V3 kd() const { return V3{r[3].x, r[3].y, r[3].z}; }
-    PTD float ns() const { return r[3].w; }
-    PTD V3 ks() const { return V3{r[4].x, r[4].y, r[4].z}; }
-    PTD float inv_area() const { return r[4].w; }
-    PTD V3 n0() const { return V3{r[5].x, r[5].y, r[5].z}; }
-    PTD V3 n1() const { return V3{r[5].w, r[6].x, r[6].y}; }
-    PTD V3 n2() const { return V3{r[6].z, r[6].w, r[7].w}; }
-    PTD V3 lemit() const { return V3{r[7].x, r[7].y, r[7].z}; }
+    PTD float inv_area() const { return r[3].x; }
+    PTD V3 lemit() const { return V3{r[3].y, r[3].z, r[3].w}; }
+    PTD V3 n0() const { return V3{nr[0].x, nr[0].y, nr[0].z}; }
+    PTD V3 n1() const { return V3{nr[0].w, nr[1].x, nr[1].y}; }
+    PTD V3 n2() const { return V3{nr[1].z, nr[1].w, nr[2].x}; }
+    PTD V3 kd() const { return V3{m[0].x, m[0].y, m[0].z}; }
+    PTD float ns() const { return m[0].w; }
+    PTD V3 ks() const { return V3{m[1].x, m[1].y, m[1].z}; }
+    PTD int32_t tex() const { return int32_t(as_u(m[1].w)); }
 };
 
 struct LightRec {

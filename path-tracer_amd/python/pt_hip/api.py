@@ -60,14 +60,15 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("closest_rays", C.c_uint64), ("any_rays", C.c_uint64), ("exact_retraces", C.c_uint64),
                 ("nodes_fetched", C.c_uint64 * 3), ("tris_fetched", C.c_uint64 * 3), ("seconds", C.c_double), ("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8),
-                ("nodes_from_lds", C.c_uint64 * 3), ("samples_per_pass", C.c_uint32), ("passes", C.c_uint32)]
+                ("nodes_from_lds", C.c_uint64 * 3), ("samples_per_pass", C.c_uint32), ("passes", C.c_uint32),
+                ("shaded_hits", C.c_uint64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k in ("paths", "closest_rays", "any_rays", "exact_retraces", "seconds")}
         d["nodes_fetched"] = {n: self.nodes_fetched[i] for i, n in enumerate(("generate", "extend", "shadow"))}
         d["tris_fetched"] = {n: self.tris_fetched[i] for i, n in enumerate(("generate", "extend", "shadow"))}
         d["nodes_from_lds"] = {n: self.nodes_from_lds[i] for i, n in enumerate(("generate", "extend", "shadow"))}
-        d["samples_per_pass"], d["passes"] = self.samples_per_pass, self.passes
+        d["samples_per_pass"], d["passes"], d["shaded_hits"] = self.samples_per_pass, self.passes, self.shaded_hits
         d["kernel_ms"] = {KERNEL_NAMES[i]: self.kernel_ms[i] for i in range(8) if self.kernel_launches[i]}
         d["kernel_launches"] = {KERNEL_NAMES[i]: self.kernel_launches[i] for i in range(8) if self.kernel_launches[i]}
         return d

@@ -82,6 +82,6 @@ for k in ("library_fast", "veach_fast", "veach_exact", "library_exact"):
     d = json.load(open(os.path.join(P, "r3_%s_bench_%s.json" % (new, k))))
     r = d["roofline"]
     print(k, "Mrays/s %.0f" % d["value"], "samples/s %.3g" % d["samples_per_s"], "ms/step %.0f" % d["ms_per_step"], "| roofline", r["kernel"],
-          "frac", r["frac"], "stale", r["stale"], "avg launch %.3f ms" % r["avg_launch_ms"], "lane accesses/unit %.1f" % r["lane_accesses_per_unit"], "bytes/unit %.0f" % r["hbm"]["bytes_per_unit"], "units/launch %.3g" % r["units_per_launch"],
+          "frac", r["frac"], "stale", r["stale"], "avg launch %.3f ms" % r["avg_launch_ms"], "lane accesses/unit %.1f" % r["gather"]["lane_accesses_per_unit"], "bytes/unit %.0f" % r["hbm"]["bytes_per_unit"], "units/launch %.3g" % r["units_per_launch"],
           "| cpu", d.get("cpu_baseline", {}).get("value"))
 print(open(os.path.join(P, "r3_%s_rocprof_bench_library_fast.txt" % new)).read().split("\n")[2])
