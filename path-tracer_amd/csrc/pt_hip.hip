@@ -278,8 +278,10 @@ int validate(const pt_scene_desc* d, uint32_t& depth_out) {
     }
     if (leaf_prims != d->n_tris) return fail(PT_ERR_INVALID, "BVH leaves do not cover every triangle exactly once");
     // reference order: one deferred sibling per level; ordered mode: up to three deferred slots per two levels
-    if (depth + 2 > uint32_t(kMaxStack) || 3 * ((depth + 1) / 2) + 4 > uint32_t(kMaxStack))
-        return fail(PT_ERR_LIMIT, "BVH deeper than the traversal stack (" + std::to_string(2 * ((kMaxStack - 4) / 3)) + " levels)");
+    // (an 8-wide navigation node: up to seven deferred slots per three levels)
+    const uint32_t ordered_need = kWide == 8 ? 7 * ((depth + 2) / 3) + 8 : 3 * ((depth + 1) / 2) + 4;
+    if (depth + 2 > uint32_t(kMaxStack) || ordered_need > uint32_t(kMaxStack))
+        return fail(PT_ERR_LIMIT, "BVH deeper than the traversal stack (" + std::to_string(kWide == 8 ? 3 * ((kMaxStack - 8) / 7) : 2 * ((kMaxStack - 4) / 3)) + " levels)");
     depth_out = depth;
     return PT_OK;
 }
@@ -407,151 +409,84 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     }
     // the second child of a fat leaf: no header of its own
     auto headless = [&](uint32_t i) { return i != 0u && fat[parent[i]] && i == d->nodes[parent[i]].first + 1u; };
-    uint64_t n_slots64 = 0;
-    for (uint32_t i = 0; i < d->n_nodes; ++i) {
-        const pt_bvh_node& b = d->nodes[i];
-        slot_of[i] = uint32_t(n_slots64);
-        if (b.count) n_slots64 += (headless(i) ? 0u : 1u) + b.count;
-    }
-    if (n_slots64 > kLeafFirstMask) return fail(PT_ERR_LIMIT, "triangles + leaves exceed 2^27-1 leaf-array records");
-    slot_of[d->n_nodes] = uint32_t(n_slots64);
-    clk.lap("leaf slots");
-    // reference-order nodes
-    if (int rc = fill_upload<float4>(
-            s, d->n_nodes, [](size_t u) { return 2 * u; }, &dev.nodes, [&](size_t i, float4* o) {
-                const pt_bvh_node& b = d->nodes[i];
-                uint32_t first = b.count ? slot_of[i] + (headless(uint32_t(i)) ? 0u : 1u) : b.first, count = b.count;
-                float ff, fc;
-                std::memcpy(&ff, &first, 4);
-                std::memcpy(&fc, &count, 4);
-                o[0] = make_float4(b.lo[0], b.lo[1], b.lo[2], b.hi[0]);
-                o[1] = make_float4(b.hi[1], b.hi[2], ff, fc);
-            }))
-        return rc;
-    // leaf array: unit = node (interior nodes contribute nothing)
-    std::atomic<uint32_t> unreliable{0};
-    if (int rc = fill_upload<float4>(
-            s, d->n_nodes, [&](size_t u) { return 3 * size_t(slot_of[u]); }, &dev.tris, [&](size_t i, float4* h) {
-                const pt_bvh_node& b = d->nodes[i];
-                if (!b.count) return;
-                if (!headless(uint32_t(i))) {
-                    const uint32_t flags = (i == 0) ? kLeafUntested : 0u;
-                    float ffl;
-                    std::memcpy(&ffl, &flags, 4);
-                    const pt_bvh_node& pb = d->nodes[parent[i]];
-                    h[0] = make_float4(pb.lo[0], pb.lo[1], pb.lo[2], pb.hi[0]);
-                    h[1] = make_float4(pb.hi[1], pb.hi[2], ffl, 0.0f);
-                    h[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    h += 3;
+
+    // ---- navigation tree of the ordered traversal: which binary nodes become navigation nodes, and their numbers.
+    // Collapse: the navigation node of binary interior node N starts from N's two children and opens, one at a time,
+    // the interior slot with the largest surface (the box a ray is most likely to enter anyway) until it has kWide
+    // slots or only leaves and fat leaves are left; slots stay in the binary tree's left-to-right order.  The
+    // interior slots are navigation nodes in turn.  (Against taking N's grandchildren: 0.4 - 2 % more rays per second;
+    // the sweep builder's trees are balanced enough that the two rarely differ.)
+    auto leaf_like = [&](uint32_t c) { return d->nodes[c].count != 0u || fat[c]; };
+    auto surface = [&](uint32_t c) {
+        const pt_bvh_node& b = d->nodes[c];
+        const double x = double(b.hi[0]) - double(b.lo[0]), y = double(b.hi[1]) - double(b.lo[1]), z = double(b.hi[2]) - double(b.lo[2]);
+        return x * y + y * z + z * x;
+    };
+    auto collapse = [&](uint32_t n, uint32_t* slots) -> int {
+        int ns = 0;
+        slots[ns++] = d->nodes[n].first;
+        slots[ns++] = d->nodes[n].first + 1u;
+        while (ns < kWide) {
+            int open = -1;
+            double best = -1.0;
+            for (int k = 0; k < ns; ++k) {
+                if (leaf_like(slots[k])) continue;
+                const double a = surface(slots[k]);
+                if (a > best) {
+                    best = a;
+                    open = k;
                 }
-                for (uint32_t k = 0; k < b.count; ++k) {
-                    const uint32_t prim = d->prim_ids[b.first + k];
-                    const uint32_t prim_word = prim | (tri_has_normals(d, prim) ? kPrimHasNormals : 0u) | (d->light_id[prim] >= 0 ? kPrimEmitter : 0u);
-                    const float* p0 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 0] - 1);
-                    const float* p1 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 1] - 1);
-                    const float* p2 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 2] - 1);
-                    float fp;
-                    std::memcpy(&fp, &prim_word, 4);
-                    float4* o = h + 3 * size_t(k);
-                    o[0] = make_float4(p0[0], p0[1], p0[2], fp);
-                    o[1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.0f);
-                    o[2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f);
-                    if (unreliable_triangle(&o[1].x, &o[2].x)) unreliable.fetch_add(1u, std::memory_order_relaxed);
-                }
-            }))
-        return rc;
-    s->reference_order_only = unreliable.load() != 0u;
-    if (clk.on && s->reference_order_only)
-        std::fprintf(stderr, "pt_hip_scene_create: %u needle-shaped or collapsed triangles: every query runs in reference order\n", unreliable.load());
-    clk.lap("binary nodes + leaf array");
-    // navigation nodes of the ordered traversal: 4-wide, 64 bytes each, slot boxes on a 16-bit grid over the root box,
-    // rounded outwards (box_cheap in traverse.h)
-    {
-        const pt_bvh_node& root = d->nodes[0];
-        double org[3], step[3];
-        for (int a = 0; a < 3; ++a) {
-            dev.q_org[a] = root.lo[a];
-            // spacing rounded up so that grid point 65535 lies at or beyond the far face; never zero (flat scenes)
-            const float st = float(std::max((double(root.hi[a]) - double(root.lo[a])) / 65535.0 * (1.0 + 1e-6), 1e-30));
-            dev.q_step[a] = st;
-            org[a] = dev.q_org[a];
-            step[a] = dev.q_step[a];
-        }
-        auto q_lo = [&](float v, int a) -> uint32_t {  // largest grid point at or below v, minus one step of safety
-            const double g = std::floor((double(v) - org[a]) / step[a]) - 1.0;
-            return uint32_t(std::min(65535.0, std::max(0.0, g)));
-        };
-        auto q_hi = [&](float v, int a) -> uint32_t {  // smallest grid point at or above v, plus one step of safety
-            const double g = std::ceil((double(v) - org[a]) / step[a]) + 1.0;
-            return uint32_t(std::min(65535.0, std::max(0.0, g)));
-        };
-        // Collapse: the navigation node of binary interior node N starts from N's two children and opens, one at a time,
-        // the interior slot with the largest surface (the box a ray is most likely to enter anyway) until it has four
-        // slots or only leaves and fat leaves are left; slots stay in the binary tree's left-to-right order.  The
-        // interior slots are navigation nodes in turn.  (Against taking N's grandchildren: 0.4 - 2 % more rays per second;
-        // the sweep builder's trees are balanced enough that the two rarely differ.)  They are numbered in the order of their binary node index (the
-        // reference's numbering keeps a subtree contiguous) when every child index exceeds its parent's, as in every tree
-        // a top-down builder emits -- one streaming pass; otherwise depth-first.
-        auto leaf_like = [&](uint32_t c) { return d->nodes[c].count != 0u || fat[c]; };
-        auto surface = [&](uint32_t c) {
-            const pt_bvh_node& b = d->nodes[c];
-            const double x = double(b.hi[0]) - double(b.lo[0]), y = double(b.hi[1]) - double(b.lo[1]), z = double(b.hi[2]) - double(b.lo[2]);
-            return x * y + y * z + z * x;
-        };
-        auto collapse = [&](uint32_t n, uint32_t* slots) -> int {
-            int ns = 0;
-            slots[ns++] = d->nodes[n].first;
-            slots[ns++] = d->nodes[n].first + 1u;
-            while (ns < kWide) {
-                int open = -1;
-                double best = -1.0;
-                for (int k = 0; k < ns; ++k) {
-                    if (leaf_like(slots[k])) continue;
-                    const double a = surface(slots[k]);
-                    if (a > best) {
-                        best = a;
-                        open = k;
-                    }
-                }
-                if (open < 0) break;
-                const uint32_t c = slots[open];
-                for (int k = ns; k > open + 1; --k) slots[k] = slots[k - 1];
-                slots[open] = d->nodes[c].first;
-                slots[open + 1] = d->nodes[c].first + 1u;
-                ++ns;
             }
-            return ns;
-        };
-        std::vector<uint32_t> wide_id(d->n_nodes, kEmptyRef), order;
-        {
-            bool forward = true;
-            for (uint32_t i = 0; i < d->n_nodes && forward; ++i)
-                if (d->nodes[i].count == 0u && d->nodes[i].first <= i) forward = false;
-            if (forward) {
-                std::vector<uint8_t> is_nav(d->n_nodes, 0);
-                if (!leaf_like(0u)) is_nav[0] = 1;
-                for (uint32_t i = 0; i < d->n_nodes; ++i) {
-                    if (!is_nav[i]) continue;
-                    wide_id[i] = uint32_t(order.size());
-                    order.push_back(i);
-                    uint32_t slots[kWide];
-                    const int ns = collapse(i, slots);
-                    for (int k = 0; k < ns; ++k)
-                        if (!leaf_like(slots[k])) is_nav[slots[k]] = 1;
-                }
-            } else {
-                std::vector<uint32_t> stack;
-                if (!leaf_like(0u)) stack.push_back(0u);
-                while (!stack.empty()) {
-                    const uint32_t n = stack.back();
-                    stack.pop_back();
-                    wide_id[n] = uint32_t(order.size());
-                    order.push_back(n);
-                    uint32_t slots[kWide];
-                    const int ns = collapse(n, slots);
-                    for (int k = ns - 1; k >= 0; --k)
-                        if (!leaf_like(slots[k])) stack.push_back(slots[k]);
-                }
+            if (open < 0) break;
+            const uint32_t c = slots[open];
+            for (int k = ns; k > open + 1; --k) slots[k] = slots[k - 1];
+            slots[open] = d->nodes[c].first;
+            slots[open + 1] = d->nodes[c].first + 1u;
+            ++ns;
+        }
+        return ns;
+    };
+    // triangles of a leaf-like slot (a leaf, or a fat leaf: both children together)
+    auto unit_tris = [&](uint32_t c) -> uint32_t {
+        const pt_bvh_node& b = d->nodes[c];
+        return b.count ? b.count : d->nodes[b.first].count + d->nodes[b.first + 1].count;
+    };
+    // `order`: binary node of navigation node 0, 1, ...; `units`: the leaves and fat leaves in the order of their records in
+    // the leaf array (a unit = one header record followed by its triangles)
+    std::vector<uint32_t> wide_id(d->n_nodes, kEmptyRef), order, units;
+    std::vector<uint32_t> child_base, leaf_base;  // 8-wide only, per navigation node: number of its first interior slot, record of its first leaf slot
+    if (leaf_like(0u)) units.push_back(0u);
+    if (kWide == 4) {
+        // Numbered in the order of their binary node index (the reference's numbering keeps a subtree contiguous) when every
+        // child index exceeds its parent's, as in every tree a top-down builder emits -- one streaming pass; otherwise
+        // depth-first.  Leaf records in the order of the binary nodes.
+        bool forward = true;
+        for (uint32_t i = 0; i < d->n_nodes && forward; ++i)
+            if (d->nodes[i].count == 0u && d->nodes[i].first <= i) forward = false;
+        if (forward) {
+            std::vector<uint8_t> is_nav(d->n_nodes, 0);
+            if (!leaf_like(0u)) is_nav[0] = 1;
+            for (uint32_t i = 0; i < d->n_nodes; ++i) {
+                if (!is_nav[i]) continue;
+                wide_id[i] = uint32_t(order.size());
+                order.push_back(i);
+                uint32_t slots[kWide];
+                const int ns = collapse(i, slots);
+                for (int k = 0; k < ns; ++k)
+                    if (!leaf_like(slots[k])) is_nav[slots[k]] = 1;
+            }
+        } else {
+            std::vector<uint32_t> stack;
+            if (!leaf_like(0u)) stack.push_back(0u);
+            while (!stack.empty()) {
+                const uint32_t n = stack.back();
+                stack.pop_back();
+                wide_id[n] = uint32_t(order.size());
+                order.push_back(n);
+                uint32_t slots[kWide];
+                const int ns = collapse(n, slots);
+                for (int k = ns - 1; k >= 0; --k)
+                    if (!leaf_like(slots[k])) stack.push_back(slots[k]);
             }
         }
         // The navigation nodes a ray is most likely to visit come first: starting at the root, the node with the largest
@@ -578,32 +513,239 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             order.swap(top);
             for (size_t i = 0; i < order.size(); ++i) wide_id[order[i]] = uint32_t(i);
         }
-        dev.n_treelet = uint32_t(std::min<size_t>(kTreeletMax, order.size()));
-        auto ref_of = [&](uint32_t ni) -> uint32_t {
-            const pt_bvh_node& b = d->nodes[ni];
-            if (b.count) return kLeafBit | (b.count << kLeafCountShift) | slot_of[ni];
-            if (fat[ni]) return kLeafBit | ((d->nodes[b.first].count + d->nodes[b.first + 1].count) << kLeafCountShift) | slot_of[b.first];
-            return wide_id[ni];
+        for (uint32_t i = 1; i < d->n_nodes; ++i)
+            if (leaf_like(i) && !(d->nodes[i].count && fat[parent[i]])) units.push_back(i);  // a fat leaf's children belong to its unit
+    } else if (!leaf_like(0u)) {
+        // 8-wide: references are implicit (traverse.h, Nav8), so the interior slots of a node are numbered together, and
+        // its leaf slots follow one another in the leaf array, at the moment the node is EXPANDED.  Nodes are expanded by
+        // surface, largest first, until kTreeletMax are numbered (the most visited ones come first, for the LDS treelet);
+        // from there on depth-first from each of the nodes still waiting, so that a subtree's records stay together.
+        order.push_back(0u);
+        wide_id[0] = 0u;
+        uint32_t next_record = 0;
+        auto expand = [&](uint32_t n, std::vector<uint32_t>& fresh) {
+            const uint32_t id = wide_id[n];
+            if (child_base.size() <= id) {
+                child_base.resize(size_t(id) + 1, 0u);
+                leaf_base.resize(size_t(id) + 1, 0u);
+            }
+            child_base[id] = uint32_t(order.size());
+            leaf_base[id] = next_record;
+            uint32_t slots[kWide];
+            const int ns = collapse(n, slots);
+            for (int k = 0; k < ns; ++k) {
+                const uint32_t c = slots[k];
+                if (leaf_like(c)) {
+                    units.push_back(c);
+                    next_record += 1u + unit_tris(c);
+                } else {
+                    wide_id[c] = uint32_t(order.size());
+                    order.push_back(c);
+                    fresh.push_back(c);
+                }
+            }
         };
+        std::priority_queue<std::pair<double, uint32_t>> frontier;
+        frontier.push({surface(0u), 0u});
+        std::vector<uint32_t> fresh;
+        while (!frontier.empty() && order.size() < kTreeletMax) {
+            const uint32_t n = frontier.top().second;
+            frontier.pop();
+            fresh.clear();
+            expand(n, fresh);
+            for (uint32_t c : fresh) frontier.push({surface(c), c});
+        }
+        std::vector<uint32_t> waiting;
+        while (!frontier.empty()) {
+            waiting.push_back(frontier.top().second);
+            frontier.pop();
+        }
+        std::sort(waiting.begin(), waiting.end(), [&](uint32_t a, uint32_t b) { return wide_id[a] < wide_id[b]; });
+        std::vector<uint32_t> stack;
+        for (uint32_t root_of : waiting) {
+            stack.assign(1, root_of);
+            while (!stack.empty()) {
+                const uint32_t n = stack.back();
+                stack.pop_back();
+                fresh.clear();
+                expand(n, fresh);
+                for (size_t k = fresh.size(); k-- > 0;) stack.push_back(fresh[k]);
+            }
+        }
+        child_base.resize(order.size(), 0u);
+        leaf_base.resize(order.size(), 0u);
+    }
+    // records of the leaf array: unit u starts at unit_record[u]; slot_of[i] = first record of leaf node i (its header, or
+    // its first triangle when it is the second child of a fat leaf)
+    std::vector<uint32_t> unit_record(units.size() + 1, 0);
+    {
+        uint64_t n_slots64 = 0;
+        for (size_t u = 0; u < units.size(); ++u) {
+            unit_record[u] = uint32_t(n_slots64);
+            const uint32_t c = units[u];
+            const pt_bvh_node& b = d->nodes[c];
+            if (b.count) {
+                slot_of[c] = uint32_t(n_slots64);
+            } else {
+                slot_of[b.first] = uint32_t(n_slots64);
+                slot_of[b.first + 1] = uint32_t(n_slots64) + 1u + d->nodes[b.first].count;
+            }
+            n_slots64 += 1u + unit_tris(c);
+            if (n_slots64 > kLeafFirstMask) return fail(PT_ERR_LIMIT, "triangles + leaves exceed 2^27-1 leaf-array records");
+        }
+        unit_record[units.size()] = uint32_t(n_slots64);
+    }
+    clk.lap("navigation tree + leaf slots");
+    // reference-order nodes
+    if (int rc = fill_upload<float4>(
+            s, d->n_nodes, [](size_t u) { return 2 * u; }, &dev.nodes, [&](size_t i, float4* o) {
+                const pt_bvh_node& b = d->nodes[i];
+                uint32_t first = b.count ? slot_of[i] + (headless(uint32_t(i)) ? 0u : 1u) : b.first, count = b.count;
+                float ff, fc;
+                std::memcpy(&ff, &first, 4);
+                std::memcpy(&fc, &count, 4);
+                o[0] = make_float4(b.lo[0], b.lo[1], b.lo[2], b.hi[0]);
+                o[1] = make_float4(b.hi[1], b.hi[2], ff, fc);
+            }))
+        return rc;
+    // leaf array: unit = a leaf or a fat leaf: header {parent box} + its triangles
+    std::atomic<uint32_t> unreliable{0};
+    if (int rc = fill_upload<float4>(
+            s, units.size(), [&](size_t u) { return 3 * size_t(unit_record[u]); }, &dev.tris, [&](size_t u, float4* h) {
+                const uint32_t c = units[u];
+                const pt_bvh_node& cb = d->nodes[c];
+                // the box the reference tests before it reaches these triangles: the leaf's parent (for a fat leaf, the fat
+                // node itself: the parent of both of its leaves)
+                const bool is_root_leaf = c == 0u && cb.count != 0u;
+                const pt_bvh_node& pb = cb.count ? d->nodes[parent[c]] : cb;
+                const uint32_t flags = is_root_leaf ? kLeafUntested : 0u;
+                float ffl;
+                std::memcpy(&ffl, &flags, 4);
+                h[0] = make_float4(pb.lo[0], pb.lo[1], pb.lo[2], pb.hi[0]);
+                h[1] = make_float4(pb.hi[1], pb.hi[2], ffl, 0.0f);
+                h[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                float4* o = h + 3;
+                const uint32_t leaves[2] = {cb.count ? c : cb.first, cb.count ? c : cb.first + 1u};
+                for (int l = 0; l < (cb.count ? 1 : 2); ++l) {
+                    const pt_bvh_node& b = d->nodes[leaves[l]];
+                    for (uint32_t k = 0; k < b.count; ++k, o += 3) {
+                        const uint32_t prim = d->prim_ids[b.first + k];
+                        const uint32_t prim_word = prim | (tri_has_normals(d, prim) ? kPrimHasNormals : 0u) | (d->light_id[prim] >= 0 ? kPrimEmitter : 0u);
+                        const float* p0 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 0] - 1);
+                        const float* p1 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 1] - 1);
+                        const float* p2 = d->verts + 3 * size_t(d->vi[3 * size_t(prim) + 2] - 1);
+                        float fp;
+                        std::memcpy(&fp, &prim_word, 4);
+                        o[0] = make_float4(p0[0], p0[1], p0[2], fp);
+                        o[1] = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], 0.0f);
+                        o[2] = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], 0.0f);
+                        if (unreliable_triangle(&o[1].x, &o[2].x)) unreliable.fetch_add(1u, std::memory_order_relaxed);
+                    }
+                }
+            }))
+        return rc;
+    s->reference_order_only = unreliable.load() != 0u;
+    if (clk.on && s->reference_order_only)
+        std::fprintf(stderr, "pt_hip_scene_create: %u needle-shaped or collapsed triangles: every query runs in reference order\n", unreliable.load());
+    clk.lap("binary nodes + leaf array");
+    // navigation nodes of the ordered traversal
+    {
+        const pt_bvh_node& root = d->nodes[0];
+        double org[3], step[3];
+        for (int a = 0; a < 3; ++a) {
+            dev.q_org[a] = root.lo[a];
+            // spacing rounded up so that grid point 65535 lies at or beyond the far face; never zero (flat scenes)
+            const float st = float(std::max((double(root.hi[a]) - double(root.lo[a])) / 65535.0 * (1.0 + 1e-6), 1e-30));
+            dev.q_step[a] = st;
+            org[a] = dev.q_org[a];
+            step[a] = dev.q_step[a];
+        }
+        auto q_lo = [&](float v, int a) -> uint32_t {  // largest grid point at or below v, minus one step of safety
+            const double g = std::floor((double(v) - org[a]) / step[a]) - 1.0;
+            return uint32_t(std::min(65535.0, std::max(0.0, g)));
+        };
+        auto q_hi = [&](float v, int a) -> uint32_t {  // smallest grid point at or above v, plus one step of safety
+            const double g = std::ceil((double(v) - org[a]) / step[a]) + 1.0;
+            return uint32_t(std::min(65535.0, std::max(0.0, g)));
+        };
+        auto leaf_ref = [&](uint32_t ni) -> uint32_t {  // of a leaf or fat leaf
+            const pt_bvh_node& b = d->nodes[ni];
+            return kLeafBit | (unit_tris(ni) << kLeafCountShift) | slot_of[b.count ? ni : b.first];
+        };
+        auto ref_of = [&](uint32_t ni) -> uint32_t { return leaf_like(ni) ? leaf_ref(ni) : wide_id[ni]; };
+        dev.n_treelet = uint32_t(std::min<size_t>(kTreeletMax, order.size()));
+        std::atomic<int> bad{0};
         if (int rc = fill_upload<uint4>(
-                s, std::max<size_t>(order.size(), 1), [](size_t u) { return size_t(kWide) * u; }, &dev.qnodes, [&](size_t wi, uint4* w) {
-                    for (int k = 0; k < kWide; ++k) w[k] = make_uint4(0u, 0u, 0u, kEmptyRef);
+                s, std::max<size_t>(order.size(), 1), [](size_t u) { return size_t(kNavVec4) * u; }, &dev.qnodes, [&](size_t wi, uint4* w) {
+                    for (int k = 0; k < kNavVec4; ++k) w[k] = make_uint4(0u, 0u, 0u, kWide == 4 ? kEmptyRef : 0u);
                     if (wi >= order.size()) return;  // a scene whose root is a leaf has no navigation node
                     const uint32_t n = order[wi];
-                    int ns = 0;
-                    auto put = [&](uint32_t ci) {
-                        const pt_bvh_node& c = d->nodes[ci];
-                        uint4& o = w[ns++];
-                        o.x = q_lo(c.lo[0], 0) | (q_hi(c.hi[0], 0) << 16);
-                        o.y = q_lo(c.lo[1], 1) | (q_hi(c.hi[1], 1) << 16);
-                        o.z = q_lo(c.lo[2], 2) | (q_hi(c.hi[2], 2) << 16);
-                        o.w = ref_of(ci);
-                    };
                     uint32_t slots[kWide];
                     const int n_slots = collapse(n, slots);
-                    for (int k = 0; k < n_slots; ++k) put(slots[k]);
+                    if (kWide == 4) {
+                        // 64 bytes: per slot the box on a 16-bit grid over the root box, rounded outwards, and its reference
+                        for (int k = 0; k < n_slots; ++k) {
+                            const pt_bvh_node& c = d->nodes[slots[k]];
+                            uint4& o = w[k];
+                            o.x = q_lo(c.lo[0], 0) | (q_hi(c.hi[0], 0) << 16);
+                            o.y = q_lo(c.lo[1], 1) | (q_hi(c.hi[1], 1) << 16);
+                            o.z = q_lo(c.lo[2], 2) | (q_hi(c.hi[2], 2) << 16);
+                            o.w = ref_of(slots[k]);
+                        }
+                        return;
+                    }
+                    // 80 bytes (traverse.h, Nav8): an 8-bit grid over this node's own box, origin = its lower corner
+                    const pt_bvh_node& nb = d->nodes[n];
+                    uint32_t ebits[3];
+                    double sp[3];
+                    for (int a = 0; a < 3; ++a) {
+                        const double extent = double(nb.hi[a]) - double(nb.lo[a]);
+                        int k = -126;
+                        if (extent > 0.0) k = std::max(-126, int(std::ceil(std::log2(extent / 252.0))));
+                        while (std::ldexp(253.0, k) < extent) ++k;   // (log2 rounding)
+                        if (k > 127) bad.store(1);
+                        ebits[a] = uint32_t(k + 127);
+                        sp[a] = std::ldexp(1.0, k);
+                    }
+                    float px = nb.lo[0], py = nb.lo[1], pz = nb.lo[2];
+                    std::memcpy(&w[0].x, &px, 4);
+                    std::memcpy(&w[0].y, &py, 4);
+                    std::memcpy(&w[0].z, &pz, 4);
+                    w[0].w = ebits[0] | (ebits[1] << 8) | (ebits[2] << 16);
+                    w[1].x = child_base[wi];
+                    w[1].y = leaf_base[wi];
+                    uint32_t expect_child = child_base[wi], expect_leaf = leaf_base[wi];
+                    for (int k = 0; k < n_slots; ++k) {
+                        const uint32_t c = slots[k];
+                        const pt_bvh_node& cb = d->nodes[c];
+                        uint32_t meta;
+                        if (leaf_like(c)) {
+                            meta = unit_tris(c);
+                            if (slot_of[cb.count ? c : cb.first] != expect_leaf || meta == 0u || meta > 15u) bad.store(2);
+                            expect_leaf += 1u + meta;
+                        } else {
+                            meta = kNav8Interior;
+                            if (wide_id[c] != expect_child) bad.store(3);
+                            ++expect_child;
+                        }
+                        uint32_t& mw = k < 4 ? w[1].z : w[1].w;
+                        mw |= meta << (8 * (k & 3));
+                        for (int a = 0; a < 3; ++a) {
+                            const double lo = (double(cb.lo[a]) - double(nb.lo[a])) / sp[a], hi = (double(cb.hi[a]) - double(nb.lo[a])) / sp[a];
+                            const uint32_t ql = uint32_t(std::min(255.0, std::max(0.0, std::floor(lo) - 1.0)));
+                            const uint32_t qh = uint32_t(std::min(255.0, std::max(0.0, std::ceil(hi) + 1.0)));
+                            // the stored planes enclose the slot's box (exactly representable in double)
+                            if (double(nb.lo[a]) + ql * sp[a] > double(cb.lo[a]) || double(nb.lo[a]) + qh * sp[a] < double(cb.hi[a])) bad.store(4);
+                            uint4& v = w[2 + a];
+                            uint32_t& wl = k < 4 ? v.x : v.y;
+                            uint32_t& wh = k < 4 ? v.z : v.w;
+                            wl |= ql << (8 * (k & 3));
+                            wh |= qh << (8 * (k & 3));
+                        }
+                    }
                 }))
             return rc;
+        if (bad.load()) return fail(PT_ERR_INVALID, "navigation node packing failed its own check (" + std::to_string(bad.load()) + "): boxes outside the tree's nesting or not finite");
         dev.wide_root = ref_of(0);
     }
     clk.lap("navigation nodes");

@@ -23,6 +23,15 @@ constexpr uint32_t kLeafFirstMask = (1u << kLeafCountShift) - 1u;
 constexpr uint32_t kFatLeafTris = PT_FAT_LEAF_TRIS;
 static_assert(kFatLeafTris <= 15u, "the leaf reference has four bits for the triangle count");
 
+// Slots per navigation node of the ordered traversal: 4 (64-byte records, boxes on a 16-bit grid over the scene) or 8
+// (80-byte records, boxes on an 8-bit grid over the node's own box).  See traverse.h.
+#ifndef PT_NAV_WIDTH
+#define PT_NAV_WIDTH 4
+#endif
+constexpr int kWide = PT_NAV_WIDTH;
+static_assert(kWide == 4 || kWide == 8, "navigation nodes are 4- or 8-wide");
+constexpr int kNavVec4 = kWide == 8 ? 5 : 4;  // uint4 per navigation node
+
 // The first navigation nodes are the ones rays visit most (the root, then by surface); the traversal kernels serve a
 // prefix of them from LDS.  kTreeletMax bounds what the scene builder orders that way.
 constexpr uint32_t kTreeletMax = 1024;
@@ -71,8 +80,8 @@ struct DevScene {
     // ---- traversal, reference order: binary nodes, 2 x float4 each:
     //      {lo.x, lo.y, lo.z, hi.x} {hi.y, hi.z, bits(first), bits(count)}
     const float4* nodes;
-    // ---- traversal, ordered: 4-wide navigation nodes, 64 bytes = 4 x uint4 each (see box_cheap in traverse.h):
-    //      per slot {c.x, c.y, c.z, ref}, c.x = lo.x | hi.x << 16 on the grid q_org + q * q_step
+    // ---- traversal, ordered: navigation nodes, kNavVec4 x uint4 each (see box_cheap in traverse.h).  4-wide:
+    //      per slot {c.x, c.y, c.z, ref}, c.x = lo.x | hi.x << 16 on the grid q_org + q * q_step.  8-wide: see Nav8 there.
     const uint4* qnodes;
     float q_org[3], q_step[3];
     uint32_t wide_root;  // reference of the root (an interior index, or a leaf reference for tiny scenes)

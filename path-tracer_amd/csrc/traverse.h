@@ -345,8 +345,22 @@ PTD bool cheap_go(const BoxC& b, float tmin, float far) {
     return b.tn <= b.tf && b.tn <= far && __fmaf_rn(kNearTie, fabsf(b.tn), b.tf) >= tmin;
 }
 
-constexpr uint32_t kEmptyRef = 0xffffffffu;  // unused slot of a navigation node
-constexpr int kWide = 4;                      // slots per navigation node
+constexpr uint32_t kEmptyRef = 0xffffffffu;  // unused slot of a 4-wide navigation node
+
+// 8-wide navigation nodes (PT_NAV_WIDTH = 8), 80 bytes = 5 x uint4.  A node's slots are the result of opening the
+// interior slot with the largest surface until there are eight (or only leaves are left); their boxes are stored on an
+// 8-bit grid over the NODE's own box -- origin p = the box's lower corner, spacing 2^k per axis -- rounded outwards, so
+// deep nodes are resolved finer than a grid over the whole scene could, in half the bytes per slot:
+//   v0 {bits(p.x) bits(p.y) bits(p.z)  ex | ey << 8 | ez << 16}      e = biased exponent of the spacing: 2^k = bits(e << 23)
+//   v1 {child_base  leaf_base  meta[0..3]  meta[4..7]}
+//   v2 {lo.x[0..3] lo.x[4..7] hi.x[0..3] hi.x[4..7]}   v3 the same for y   v4 for z      (one byte per slot)
+// meta byte of a slot: 0 = unused; 0x80 = interior; otherwise the triangle count of a leaf (1..15).  References are
+// implicit: the interior slots of a node are navigation nodes child_base, child_base + 1, ... in slot order, and its leaf
+// slots lie one behind the other in the leaf array from record leaf_base on (one header record + count triangles each).
+// Entry and exit estimates: t = ((p + q 2^k) - o) / d = q * a + b with a = 2^k / d (exact: a power of two times the
+// ray's reciprocal) and b = (p - o) / d per node and axis; the padding of box_cheap applies unchanged, since p lies
+// inside the scene bounds and the error terms are bounded on the scale of the scene's extent over |d|.
+constexpr uint32_t kNav8Interior = 0x80u;
 
 // The top of the navigation tree in LDS.  A CU serves per-lane 16-byte loads of different addresses at about one lane
 // per clock, whatever cache level they hit in (measured: tools/gather_roof.hip; 64 lanes x 4 loads per node), and that
@@ -367,10 +381,10 @@ struct Treelet {
     uint32_t n;
 };
 
-// By all threads of a workgroup, before any of them traverses.  s_nodes: kTreelet * kWide uint4 of LDS.
+// By all threads of a workgroup, before any of them traverses.  s_nodes: kTreelet * kNavVec4 uint4 of LDS.
 PTD Treelet treelet_fill(const DevScene& sc, uint4* s_nodes) {
     const uint32_t n = min(kTreelet, sc.n_treelet);
-    for (uint32_t i = threadIdx.x; i < n * kWide; i += blockDim.x) s_nodes[i] = sc.qnodes[i];
+    for (uint32_t i = threadIdx.x; i < n * kNavVec4; i += blockDim.x) s_nodes[i] = sc.qnodes[i];
     __syncthreads();
     return Treelet{(const lds_u4*)reinterpret_cast<u32x4*>(s_nodes), n};
 }
@@ -381,25 +395,96 @@ constexpr uint32_t kNodeHist = 1u << 20;
 __device__ uint32_t g_node_hist[kNodeHist];
 #endif
 
-// the four slots of navigation node `cur`
+// the four slots of 4-wide navigation node `cur`
 PTD void nav_fetch(const DevScene& sc, const Treelet& tl, uint32_t cur, uint4& c0, uint4& c1, uint4& c2, uint4& c3) {
 #ifdef PT_NODE_HIST
     atomicAdd(&g_node_hist[min(cur, kNodeHist - 1u)], 1u);
 #endif
     if (cur < tl.n) {
-        const lds_u4* w = tl.nodes + kWide * cur;
+        const lds_u4* w = tl.nodes + 4 * cur;
         const u32x4 a = w[0], b = w[1], c = w[2], d = w[3];
         c0 = make_uint4(a.x, a.y, a.z, a.w);
         c1 = make_uint4(b.x, b.y, b.z, b.w);
         c2 = make_uint4(c.x, c.y, c.z, c.w);
         c3 = make_uint4(d.x, d.y, d.z, d.w);
     } else {
-        const uint4* w = sc.qnodes + kWide * size_t(cur);
+        const uint4* w = sc.qnodes + 4 * size_t(cur);
         c0 = w[0];
         c1 = w[1];
         c2 = w[2];
         c3 = w[3];
     }
+}
+
+// the five quarters of 8-wide navigation node `cur`
+struct Nav8 {
+    uint4 v0, v1, v2, v3, v4;
+    PTD void fetch(const DevScene& sc, const Treelet& tl, uint32_t cur) {
+#ifdef PT_NODE_HIST
+        atomicAdd(&g_node_hist[min(cur, kNodeHist - 1u)], 1u);
+#endif
+        if (cur < tl.n) {
+            const lds_u4* w = tl.nodes + 5 * cur;
+            const u32x4 a = w[0], b = w[1], c = w[2], d = w[3], e = w[4];
+            v0 = make_uint4(a.x, a.y, a.z, a.w);
+            v1 = make_uint4(b.x, b.y, b.z, b.w);
+            v2 = make_uint4(c.x, c.y, c.z, c.w);
+            v3 = make_uint4(d.x, d.y, d.z, d.w);
+            v4 = make_uint4(e.x, e.y, e.z, e.w);
+        } else {
+            const uint4* w = sc.qnodes + 5 * size_t(cur);
+            v0 = w[0];
+            v1 = w[1];
+            v2 = w[2];
+            v3 = w[3];
+            v4 = w[4];
+        }
+    }
+};
+
+// Per-ray constants of the 8-wide box test: the reciprocal direction and the per-axis padding of box_cheap, signed like
+// the direction (d > 0: the lo plane is met first and gets b - pad, the hi plane b + pad).
+struct CheapRay8 {
+    V3 y, e;
+    PTD void set(const DevScene& sc, const RayPre& p) {
+        y = p.y;
+        const V3 org{sc.q_org[0], sc.q_org[1], sc.q_org[2]}, step{sc.q_step[0], sc.q_step[1], sc.q_step[2]};
+        const V3 rel = org - p.o;
+        const V3 c{rel.x * p.y.x, rel.y * p.y.y, rel.z * p.y.z}, a{step.x * p.y.x, step.y * p.y.y, step.z * p.y.z};
+        e = V3{copysignf(kCheapPad * (fabsf(c.x) + 65535.0f * fabsf(a.x)), p.d.x), copysignf(kCheapPad * (fabsf(c.y) + 65535.0f * fabsf(a.y)), p.d.y),
+               copysignf(kCheapPad * (fabsf(c.z) + 65535.0f * fabsf(a.z)), p.d.z)};
+    }
+};
+
+// per-node constants of the 8-wide box test
+struct NodeFrame8 {
+    V3 a, b_lo, b_hi;
+    PTD NodeFrame8(const Nav8& n, const V3& o, const CheapRay8& r) {
+        const V3 p{as_f(n.v0.x), as_f(n.v0.y), as_f(n.v0.z)};
+        const float sx = as_f((n.v0.w & 0xffu) << 23), sy = as_f((n.v0.w & 0xff00u) << 15), sz = as_f((n.v0.w & 0xff0000u) << 7);
+        a = V3{sx * r.y.x, sy * r.y.y, sz * r.y.z};
+        const V3 rel = p - o;
+        const V3 c{rel.x * r.y.x, rel.y * r.y.y, rel.z * r.y.z};
+        b_lo = c - r.e;
+        b_hi = c + r.e;
+    }
+};
+
+PTD uint32_t byte_of(uint32_t w, int k) { return (w >> (8 * k)) & 0xffu; }
+
+// slot k (0..7) of node n: its box estimates
+PTD BoxC box_cheap8(const Nav8& n, const NodeFrame8& f, int k) {
+    const uint32_t lx = k < 4 ? n.v2.x : n.v2.y, hx = k < 4 ? n.v2.z : n.v2.w;
+    const uint32_t ly = k < 4 ? n.v3.x : n.v3.y, hy = k < 4 ? n.v3.z : n.v3.w;
+    const uint32_t lz = k < 4 ? n.v4.x : n.v4.y, hz = k < 4 ? n.v4.z : n.v4.w;
+    const int j = k & 3;
+    const float x0 = __fmaf_rn(float(byte_of(lx, j)), f.a.x, f.b_lo.x), x1 = __fmaf_rn(float(byte_of(hx, j)), f.a.x, f.b_hi.x);
+    const float y0 = __fmaf_rn(float(byte_of(ly, j)), f.a.y, f.b_lo.y), y1 = __fmaf_rn(float(byte_of(hy, j)), f.a.y, f.b_hi.y);
+    const float z0 = __fmaf_rn(float(byte_of(lz, j)), f.a.z, f.b_lo.z), z1 = __fmaf_rn(float(byte_of(hz, j)), f.a.z, f.b_hi.z);
+    BoxC b;
+    b.tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    b.tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    return b;
 }
 
 // Header record of a leaf in the triangle array: {P.lo.xyz, P.hi.x} {P.hi.yz, bits(flags), 0} {unused}, P = the leaf's

@@ -96,6 +96,17 @@ struct PhaseStats {
 //   kTreeletNodes                  navigation nodes the lane type wants in LDS (0: none)
 //   inner(sc, tl, st, wc), leaf(sc, st, wc)
 //   settle(sc, [bound,] wc)        once per query when the walk has ended: true = repeat it in reference order
+// per-ray constants of the navigation test, by node width
+template <int W>
+struct NavRayOf {
+    typedef CheapRay type;
+};
+template <>
+struct NavRayOf<8> {
+    typedef CheapRay8 type;
+};
+typedef NavRayOf<kWide>::type NavRay;
+
 struct ClosestLane {
     typedef DistStack StackT;
     static constexpr int kSpillWords = 2 * DistStack::kSpill;
@@ -112,7 +123,7 @@ struct ClosestLane {
     PTD const V3& org() const { return o; }
     PTD const V3& dir() const { return d; }
     V3 o, d;
-    CheapRay cr;
+    NavRay cr;
     float tmin, tmax;
     float window;       // candidates are accepted up to here: the best hit's distance widened by kNearTie, or the ray's far end
     bool near_tie;
@@ -158,38 +169,79 @@ struct ClosestLane {
     PTD void inner(const DevScene& sc, const Treelet& tl, DistStack& st, C& wc) {
         wc.node();
         if (cur < tl.n) wc.top();
-        uint4 c0, c1, c2, c3;
-        nav_fetch(sc, tl, cur, c0, c1, c2, c3);
+#if PT_NAV_WIDTH == 8
+        inner8(sc, tl, st);
+#else
+        {
+            uint4 c0, c1, c2, c3;
+            nav_fetch(sc, tl, cur, c0, c1, c2, c3);
+            const float inf = __builtin_huge_valf(), far = cull_bound();
+            const BoxC b0 = box_cheap(c0.x, c0.y, c0.z, cr), b1 = box_cheap(c1.x, c1.y, c1.z, cr);
+            const BoxC b2 = box_cheap(c2.x, c2.y, c2.z, cr), b3 = box_cheap(c3.x, c3.y, c3.z, cr);
+            float k0 = (bool(c0.w != kEmptyRef) & cheap_go(b0, tmin, far)) ? b0.tn : inf;
+            float k1 = (bool(c1.w != kEmptyRef) & cheap_go(b1, tmin, far)) ? b1.tn : inf;
+            float k2 = (bool(c2.w != kEmptyRef) & cheap_go(b2, tmin, far)) ? b2.tn : inf;
+            float k3 = (bool(c3.w != kEmptyRef) & cheap_go(b3, tmin, far)) ? b3.tn : inf;
+            uint32_t r0 = c0.w, r1 = c1.w, r2 = c2.w, r3 = c3.w;
+            auto order = [](float& ka, uint32_t& ra, float& kb, uint32_t& rb) {  // afterwards ka <= kb
+                const bool sw = kb < ka;
+                const float kt = sw ? kb : ka;
+                const uint32_t rt = sw ? rb : ra;
+                kb = sw ? ka : kb;
+                rb = sw ? ra : rb;
+                ka = kt;
+                ra = rt;
+            };
+            order(k0, r0, k1, r1);
+            order(k2, r2, k3, r3);
+            order(k0, r0, k2, r2);
+            order(k1, r1, k3, r3);
+            order(k1, r1, k2, r2);
+            if (k3 < inf) st.push(r3, k3);
+            if (k2 < inf) st.push(r2, k2);
+            if (k1 < inf) st.push(r1, k1);
+            if (k0 < inf)
+                cur = r0;
+            else
+                next(st);
+        }
+#endif
+    }
+#if PT_NAV_WIDTH == 8
+    // The same for an 8-wide node: the slots are tried in turn; the nearest one so far is kept in registers and visited
+    // next, every other one that can hold a candidate goes onto the stack with its entry distance (in slot order: what is
+    // popped first is decided by the distances only in so far as entries beyond the best hit are dropped).
+    PTD void inner8(const DevScene& sc, const Treelet& tl, DistStack& st) {
+        Nav8 n;
+        n.fetch(sc, tl, cur);
+        const NodeFrame8 f(n, o, cr);
         const float inf = __builtin_huge_valf(), far = cull_bound();
-        const BoxC b0 = box_cheap(c0.x, c0.y, c0.z, cr), b1 = box_cheap(c1.x, c1.y, c1.z, cr);
-        const BoxC b2 = box_cheap(c2.x, c2.y, c2.z, cr), b3 = box_cheap(c3.x, c3.y, c3.z, cr);
-        float k0 = (bool(c0.w != kEmptyRef) & cheap_go(b0, tmin, far)) ? b0.tn : inf;
-        float k1 = (bool(c1.w != kEmptyRef) & cheap_go(b1, tmin, far)) ? b1.tn : inf;
-        float k2 = (bool(c2.w != kEmptyRef) & cheap_go(b2, tmin, far)) ? b2.tn : inf;
-        float k3 = (bool(c3.w != kEmptyRef) & cheap_go(b3, tmin, far)) ? b3.tn : inf;
-        uint32_t r0 = c0.w, r1 = c1.w, r2 = c2.w, r3 = c3.w;
-        auto order = [](float& ka, uint32_t& ra, float& kb, uint32_t& rb) {  // afterwards ka <= kb
-            const bool sw = kb < ka;
-            const float kt = sw ? kb : ka;
-            const uint32_t rt = sw ? rb : ra;
-            kb = sw ? ka : kb;
-            rb = sw ? ra : rb;
-            ka = kt;
-            ra = rt;
-        };
-        order(k0, r0, k1, r1);
-        order(k2, r2, k3, r3);
-        order(k0, r0, k2, r2);
-        order(k1, r1, k3, r3);
-        order(k1, r1, k2, r2);
-        if (k3 < inf) st.push(r3, k3);
-        if (k2 < inf) st.push(r2, k2);
-        if (k1 < inf) st.push(r1, k1);
-        if (k0 < inf)
-            cur = r0;
+        uint32_t next_child = n.v1.x, next_leaf = n.v1.y;
+        float best = inf;
+        uint32_t best_ref = kDone;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t meta = byte_of(k < 4 ? n.v1.z : n.v1.w, k & 3);
+            const bool interior = (meta & kNav8Interior) != 0u;
+            const uint32_t ref = interior ? next_child : (kLeafBit | (meta << kLeafCountShift) | next_leaf);
+            next_child += interior ? 1u : 0u;
+            next_leaf += (interior || meta == 0u) ? 0u : 1u + meta;
+            const BoxC b = box_cheap8(n, f, k);
+            if (bool(meta != 0u) & cheap_go(b, tmin, far)) {
+                const bool nearer = b.tn < best;
+                const float push_k = nearer ? best : b.tn;
+                const uint32_t push_r = nearer ? best_ref : ref;
+                if (push_k < inf) st.push(push_r, push_k);
+                best = nearer ? b.tn : best;
+                best_ref = nearer ? ref : best_ref;
+            }
+        }
+        if (best < inf)
+            cur = best_ref;
         else
             next(st);
     }
+#endif
 
     // A leaf: its triangles are tried at once; whether the reference reaches this leaf at all (its decision on the leaf's
     // parent box, see box_cheap in traverse.h) is settled once per ray, for the leaf of the final winner (settle()).  A
@@ -267,7 +319,7 @@ struct AnyLane {
     PTD bool leaf_ready() const { return cur > kDone; }
     PTD bool finished() const { return cur == kDone; }
     V3 o, d;
-    CheapRay cr;
+    NavRay cr;
     float tmin, tmax;
     float far_end;  // tmax widened by the near-tie window: a box the ray enters beyond it is skipped
     bool occluded;
@@ -294,33 +346,73 @@ struct AnyLane {
     PTD void inner(const DevScene& sc, const Treelet& tl, AnyStack& st, C& wc) {
         wc.node();
         if (cur < tl.n) wc.top();
-        uint4 c0, c1, c2, c3;
-        nav_fetch(sc, tl, cur, c0, c1, c2, c3);
-        const bool g0 = bool(c0.w != kEmptyRef) & cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), tmin, far_end);
-        const bool g1 = bool(c1.w != kEmptyRef) & cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), tmin, far_end);
-        const bool g2 = bool(c2.w != kEmptyRef) & cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), tmin, far_end);
-        const bool g3 = bool(c3.w != kEmptyRef) & cheap_go(box_cheap(c3.x, c3.y, c3.z, cr), tmin, far_end);
-        // the order does not change the answer; slots are listed larger subtree first, as the builder orders children for
-        // exactly this query (src/bvh.cpp:137-144), so the first slot is visited first and the last one pushed first
+#if PT_NAV_WIDTH == 8
+        inner8(sc, tl, st);
+#else
+        {
+            uint4 c0, c1, c2, c3;
+            nav_fetch(sc, tl, cur, c0, c1, c2, c3);
+            const bool g0 = bool(c0.w != kEmptyRef) & cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), tmin, far_end);
+            const bool g1 = bool(c1.w != kEmptyRef) & cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), tmin, far_end);
+            const bool g2 = bool(c2.w != kEmptyRef) & cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), tmin, far_end);
+            const bool g3 = bool(c3.w != kEmptyRef) & cheap_go(box_cheap(c3.x, c3.y, c3.z, cr), tmin, far_end);
+            // the order does not change the answer; slots are listed larger subtree first, as the builder orders children for
+            // exactly this query (src/bvh.cpp:137-144), so the first slot is visited first and the last one pushed first
+            uint32_t nxt = kDone;
+            if (g3) nxt = c3.w;
+            if (g2) {
+                if (nxt != kDone) st.push(nxt);
+                nxt = c2.w;
+            }
+            if (g1) {
+                if (nxt != kDone) st.push(nxt);
+                nxt = c1.w;
+            }
+            if (g0) {
+                if (nxt != kDone) st.push(nxt);
+                nxt = c0.w;
+            }
+            if (nxt != kDone)
+                cur = nxt;
+            else
+                next(st);
+        }
+#endif
+    }
+#if PT_NAV_WIDTH == 8
+    // 8-wide node: every slot that can hold an occluder is visited, the first one next, the others from the stack
+    PTD void inner8(const DevScene& sc, const Treelet& tl, AnyStack& st) {
+        Nav8 n;
+        n.fetch(sc, tl, cur);
+        const NodeFrame8 f(n, o, cr);
+        uint32_t next_child = n.v1.x, next_leaf = n.v1.y;
         uint32_t nxt = kDone;
-        if (g3) nxt = c3.w;
-        if (g2) {
-            if (nxt != kDone) st.push(nxt);
-            nxt = c2.w;
+        uint32_t refs[8];
+        bool go[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t meta = byte_of(k < 4 ? n.v1.z : n.v1.w, k & 3);
+            const bool interior = (meta & kNav8Interior) != 0u;
+            refs[k] = interior ? next_child : (kLeafBit | (meta << kLeafCountShift) | next_leaf);
+            next_child += interior ? 1u : 0u;
+            next_leaf += (interior || meta == 0u) ? 0u : 1u + meta;
+            go[k] = bool(meta != 0u) & cheap_go(box_cheap8(n, f, k), tmin, far_end);
         }
-        if (g1) {
-            if (nxt != kDone) st.push(nxt);
-            nxt = c1.w;
-        }
-        if (g0) {
-            if (nxt != kDone) st.push(nxt);
-            nxt = c0.w;
+        // slots are listed larger subtree first, as the builder orders children for this query (src/bvh.cpp:137-144): the
+        // first slot is visited first and the last one pushed first
+#pragma unroll
+        for (int k = 7; k >= 0; --k) {
+            if (go[k]) {
+                if (nxt != kDone) st.push(nxt);
+                nxt = refs[k];
+            }
         }
         if (nxt != kDone)
             cur = nxt;
         else
             next(st);
     }
+#endif
 
     // the first accepted triangle ends the walk; whether the reference reaches its leaf is settled afterwards
     template <class C>
@@ -677,7 +769,7 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
 // can be declared)
 template <class Lane>
 constexpr int treelet_lds_vec4() {
-    return Lane::kTreeletNodes != 0u ? int(Lane::kTreeletNodes) * kWide : 1;
+    return Lane::kTreeletNodes != 0u ? int(Lane::kTreeletNodes) * kNavVec4 : 1;
 }
 template <class Lane>
 PTD Treelet wave_treelet(const DevScene& sc, uint4* s_nodes) {
