@@ -1,8 +1,8 @@
 // Wavefront path-tracing kernels (generate+extend, extend, shade, shadow, film) and the batched ray-query kernels.
 //
 // One render pass keeps `spp_pass` samples of every pixel in flight.  A sample owns a fixed SLOT:
-//     slot = ((tile * spp_pass + s) * 64 + lane),  tile = 8x8 pixels, lane = y_in_tile * 8 + x_in_tile
-// so that a wave starts as one 8x8 pixel tile of one sample number (coherent primary rays, a wave-uniform Sobol' row).
+//     slot = ((tile * 16 + group) * spp_pass + s) * 4 + pixel of the group,  tile = 8x8 pixels, group = 2x2 pixels
+// (slot_sample / sample_slot below) so that a wave starts as 16 sample numbers of one group (coherent primary rays).
 // Radiance is accumulated per slot in `lbuf` in the reference's order (emission, then direct light, bounce by bounce:
 // src/integrator.cpp:58-73).
 //
@@ -130,6 +130,42 @@ struct PassArgs {
     float* list_pixel_sample;
 };
 
+// Slot <-> (tile, pixel of the tile, sample number of the pass).  A tile's 8x8 pixels are cut into square groups of
+// w x w pixels (w = 1 << PT_SLOT_GROUP_LOG2: 8, 4, 2 or 1), and
+//     slot = ((tile * groups + group) * spp_pass + s) * w*w + pixel of the group
+// so that 64 consecutive slots -- what a wave starts with -- are 64 / (w*w) consecutive sample numbers of one group.
+// w = 8: a wave starts as the 64 pixels of a tile at one sample number; w = 1: as 64 sample numbers of one pixel.  The
+// camera rays of a group walk the tree nearly together (merged loads, every lane in the same phase), while the Sobol'
+// numbers of ONE sample number at neighbouring pixels are correlated (the shadow rays of a wave pick the same lights):
+// measured at 512-sample passes, w = 8 / 4 / 2 / 1: k_generate_wave 46.5 / 43.9 / 40.9 / 39.4 ms on the 1.6 M-triangle
+// interior (+0 / +2.0 / +3.5 / +3.5 % rays per second in all), on veach-mis +0 / -0.6 / -0.2 / -1.2 %.
+#ifndef PT_SLOT_GROUP_LOG2
+#define PT_SLOT_GROUP_LOG2 1
+#endif
+constexpr uint32_t kGroupLog2 = PT_SLOT_GROUP_LOG2;          // log2 w
+constexpr uint32_t kGroupPixLog2 = 2u * kGroupLog2;           // log2 of the pixels of a group
+constexpr uint32_t kGroupsLog2 = 6u - kGroupPixLog2;          // log2 of the groups of a tile
+static_assert(kGroupLog2 <= 3u, "a group is at most a tile");
+// lane = y * 8 + x inside the tile
+PTD void slot_sample(const PassArgs& pa, uint32_t slot, uint32_t& tile_pos, uint32_t& lane, uint32_t& frame) {
+    const uint32_t p = slot & ((1u << kGroupPixLog2) - 1u), gs = slot >> kGroupPixLog2;
+    const uint32_t tg = gs / pa.spp_pass;
+    frame = gs - tg * pa.spp_pass;
+    const uint32_t g = tg & ((1u << kGroupsLog2) - 1u);
+    tile_pos = tg >> kGroupsLog2;
+    const uint32_t w_mask = (1u << kGroupLog2) - 1u, row_log2 = 3u - kGroupLog2;  // groups per tile row = 1 << row_log2
+    const uint32_t x = ((g & ((1u << row_log2) - 1u)) << kGroupLog2) + (p & w_mask);
+    const uint32_t y = ((g >> row_log2) << kGroupLog2) + (p >> kGroupLog2);
+    lane = y * 8u + x;
+}
+PTD uint32_t sample_slot(const PassArgs& pa, uint32_t tile_pos, uint32_t lane, uint32_t frame) {
+    const uint32_t x = lane & 7u, y = lane >> 3;
+    const uint32_t w_mask = (1u << kGroupLog2) - 1u, row_log2 = 3u - kGroupLog2;
+    const uint32_t g = ((y >> kGroupLog2) << row_log2) + (x >> kGroupLog2);
+    const uint32_t p = ((y & w_mask) << kGroupLog2) + (x & w_mask);
+    return ((((tile_pos << kGroupsLog2) + g) * pa.spp_pass + frame) << kGroupPixLog2) + p;
+}
+
 // misc[0] = exact re-traces.  Counting builds only: for kernel class k (0 generate, 1 extend, 2 shadow) the u64 at
 // word 4 + 4k holds the node records fetched and the u64 at word 6 + 4k the triangle records fetched.  Words 16..19: the
 // queries of k_finish (two u64).  The u64 at word 20 + 2k: those of class k's node records that came from the LDS treelet.
@@ -220,9 +256,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevScene sc, PassArgs pa, P
             py = uint32_t(pa.list_xy[2 * size_t(slot) + 1]);
             frame = pa.list_frame[slot];
         } else {
-            const uint32_t lane = slot & 63u, ws = slot >> 6;
-            frame = ws % pa.spp_pass;
-            const uint32_t tile = pa.tile_list ? pa.tile_list[ws / pa.spp_pass] : ws / pa.spp_pass;
+            uint32_t lane, tile_pos;
+            slot_sample(pa, slot, tile_pos, lane, frame);
+            const uint32_t tile = pa.tile_list ? pa.tile_list[tile_pos] : tile_pos;
             px = (tile % pa.tiles_x) * 8u + (lane & 7u);
             py = (tile / pa.tiles_x) * 8u + (lane >> 3);
         }
@@ -295,9 +331,9 @@ struct GenerateIo {
             py = uint32_t(pa.list_xy[2 * size_t(slot) + 1]);
             frame = pa.list_frame[slot];
         } else {
-            const uint32_t lane = slot & 63u, ws = slot >> 6;
-            frame = ws % pa.spp_pass;
-            const uint32_t tile = pa.tile_list ? pa.tile_list[ws / pa.spp_pass] : ws / pa.spp_pass;
+            uint32_t lane, tile_pos;
+            slot_sample(pa, slot, tile_pos, lane, frame);
+            const uint32_t tile = pa.tile_list ? pa.tile_list[tile_pos] : tile_pos;
             px = (tile % pa.tiles_x) * 8u + (lane & 7u);
             py = (tile / pa.tiles_x) * 8u + (lane >> 3);
         }
@@ -977,13 +1013,12 @@ __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const fl
 
     // the (up to) two patch pixels this thread accumulates: q0 = tid, q1 = tid + 256 (< 400)
     float acc[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-    for (uint32_t s = 0; s < pa.spp_pass; ++s) {
+    // one sample number: publish, then gather
+    auto splat = [&](uint32_t s, const float4& L) {
         float rec[kFilmRec];
 #pragma unroll
         for (int k = 0; k < kFilmRec; ++k) rec[k] = 0.0f;
         if (inside) {
-            const uint32_t slot = ((tile * pa.spp_pass + s) << 6) + lane;
-            const float4 L = lbuf[slot];
             const V2 j = pixel_jitter(sc, pa.frame_tab + size_t(s) * 1024u, px, py);
             const float qx = (float(int(px)) + j.x) - float(bx), qy = (float(int(py)) + j.y) - float(by);
             // ImageBlock::put drops a sample whose rounded position leaves its block (src/block.cpp:67-71); that happens
@@ -1035,6 +1070,16 @@ __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const fl
                 }
             }
         }
+    };
+    // four sample numbers at a time: their radiance loads are in flight together (64 bytes in a row per pixel in the
+    // sample-major slot order)
+    for (uint32_t s0 = 0; s0 < pa.spp_pass; s0 += 4u) {
+        float4 Lq[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) Lq[k] = inside ? lbuf[sample_slot(pa, tile, lane, min(s0 + k, pa.spp_pass - 1u))] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (s0 + k < pa.spp_pass) splat(s0 + k, Lq[k]);
     }
     const int fw = int(sc.cam.width) + 4, fh = int(sc.cam.height) + 4;
 #pragma unroll
