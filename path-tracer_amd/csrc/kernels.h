@@ -813,12 +813,23 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, PassArgs pa, HitQ hq
     zero_counters(zl, shard);
     const size_t sbase = size_t(shard) * kShard;
     const uint32_t n = hq.count[shard];
+    // the hit-list entry of the next iteration is requested before the current one is shaded: one dependent level less
+    float4 h0n{}, h1n{};
+    if (blockIdx.x * 256u + threadIdx.x < n) {
+        h0n = hq.h0[sbase + blockIdx.x * 256u + threadIdx.x];
+        h1n = hq.h1[sbase + blockIdx.x * 256u + threadIdx.x];
+    }
     for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
         const uint32_t j = base + threadIdx.x;
         ShadeOut o;
         uint32_t slot = 0;
+        const float4 h0 = h0n, h1 = h1n;
+        const uint32_t jn = j + gridDim.x * 256u;
+        if (jn < n) {
+            h0n = hq.h0[sbase + jn];
+            h1n = hq.h1[sbase + jn];
+        }
         if (j < n) {
-            const float4 h0 = hq.h0[sbase + j], h1 = hq.h1[sbase + j];
             const size_t pi = sbase + as_u(h0.x);
             const float4 a = in.a[pi], b = in.b[pi], c = in.c[pi];  // level 2 reads
             slot = in.slot[pi];
