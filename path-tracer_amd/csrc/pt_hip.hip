@@ -575,6 +575,7 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
         child_base.resize(order.size(), 0u);
         leaf_base.resize(order.size(), 0u);
     }
+    if (order.size() >= (size_t(1) << 26)) return fail(PT_ERR_LIMIT, "more than 2^26 navigation nodes");  // byte offsets of nav_fetch are 32-bit
     // records of the leaf array: unit u starts at unit_record[u]; slot_of[i] = first record of leaf node i (its header, or
     // its first triangle when it is the second child of a fat leaf)
     std::vector<uint32_t> unit_record(units.size() + 1, 0);
@@ -677,7 +678,8 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
         std::atomic<int> bad{0};
         if (int rc = fill_upload<uint4>(
                 s, std::max<size_t>(order.size(), 1), [](size_t u) { return size_t(kNavVec4) * u; }, &dev.qnodes, [&](size_t wi, uint4* w) {
-                    for (int k = 0; k < kNavVec4; ++k) w[k] = make_uint4(0u, 0u, 0u, kWide == 4 ? kEmptyRef : 0u);
+                    // (a tree with navigation nodes has two leaves at least: four records or more)
+                    for (int k = 0; k < kNavVec4; ++k) w[k] = make_uint4(0u, 0u, 0u, kWide == 4 ? empty_slot_ref(unit_record[units.size()] - 2u) : 0u);
                     if (wi >= order.size()) return;  // a scene whose root is a leaf has no navigation node
                     const uint32_t n = order[wi];
                     uint32_t slots[kWide];

@@ -8,6 +8,11 @@ namespace ptd {
 // Leaf reference in the navigation nodes: bit 31 set, triangle count in bits 27..30, the leaf's header slot in the leaf array
 // in bits 0..26 (its triangles follow in the next `count` slots).
 constexpr uint32_t kLeafBit = 0x80000000u;
+// Unused slot of a 4-wide navigation node: the box is the single grid point 0 and the reference is a leaf with no
+// triangles whose header is record `first` of the leaf array (any record but the last one and record 0: a triangle loop
+// requests record first + 1 before it looks at the count, and first = 0 would read as "walk ended").  The kernels treat
+// such a slot like any other: a ray that passes through that point of the scene's corner visits an empty leaf.
+constexpr uint32_t empty_slot_ref(uint32_t first) { return kLeafBit | first; }
 constexpr uint32_t kLeafCountShift = 27;
 constexpr uint32_t kLeafFirstMask = (1u << kLeafCountShift) - 1u;
 // Fat leaves: an interior node of the reference's tree whose two children are leaves with at most this many triangles

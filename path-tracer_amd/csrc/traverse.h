@@ -42,31 +42,42 @@ constexpr int kSpillDepth = kMaxStack - kLdsDepth;  // further entries per lane 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(5))) uint32_t private_u32;
 
+// The stack pointer is kept as the LDS byte address of the next free entry (a lane's entries are kBlock words apart), so
+// that a push or pop in the LDS part costs a compare and the move of the pointer, no address arithmetic; the index is
+// only formed for the scratch part.  The end of the LDS part is tested against a wave-uniform address: the columns of
+// a wave's lanes lie within one row, so "below the wave's first word of row ROWS" is the same for all of them.
+constexpr uint32_t kRowBytes = kBlock * 4u;
+PTD uint32_t lds_addr(const uint32_t* p) { return uint32_t(uintptr_t((const lds_u32*)p)); }
+PTD lds_u32* lds_ptr(uint32_t addr) { return (lds_u32*)uintptr_t(addr); }
 template <int ROWS>
 struct StackN {
     static constexpr int kRows = ROWS;            // entries per lane in LDS
     static constexpr int kSpill = kMaxStack - ROWS;  // further entries per lane in scratch
-    lds_u32* lds;        // &shared[0][threadIdx.x]
+    uint32_t lo;         // address of &shared[0][threadIdx.x]
+    uint32_t top;        // address of &shared[sp][threadIdx.x], also beyond the LDS rows (then only a number)
+    uint32_t lim;        // wave-uniform: address of the wave's first word of row ROWS
     private_u32* spill;  // kSpill private words, declared by the function that owns the stack (kept out of this
                          // struct so that the compiler keeps everything but the array itself in registers)
-    int sp;
     PTD void init(uint32_t* base, uint32_t* spill_words) {
-        lds = (lds_u32*)base;
+        lo = lds_addr(base);
+        top = lo;
+        lim = uint32_t(__builtin_amdgcn_readfirstlane(int(lo - 4u * (threadIdx.x & 63u)))) + uint32_t(ROWS) * kRowBytes;
         spill = (private_u32*)spill_words;
-        sp = 0;
     }
+    PTD void reset() { top = lo; }
+    PTD int over() const { return int((top - lo) / kRowBytes) - ROWS; }  // index into the scratch part
     PTD void push(uint32_t v) {
-        if (sp < ROWS)
-            lds[sp * kBlock] = v;
+        if (top < lim)
+            *lds_ptr(top) = v;
         else
-            spill[sp - ROWS] = v;
-        ++sp;
+            spill[over()] = v;
+        top += kRowBytes;
     }
     PTD uint32_t pop() {
-        --sp;
-        return (sp < ROWS) ? lds[sp * kBlock] : spill[sp - ROWS];
+        top -= kRowBytes;
+        return (top < lim) ? *lds_ptr(top) : spill[over()];
     }
-    PTD bool empty() const { return sp == 0; }
+    PTD bool empty() const { return top == lo; }
 };
 typedef StackN<kLdsDepth> Stack;
 
@@ -78,35 +89,37 @@ template <int ROWS>
 struct DistStackN {
     static constexpr int kRows = ROWS;
     static constexpr int kSpill = kMaxStack - ROWS;
-    lds_u32* lds;
-    private_u32* spill;    // kSpill references, then kSpill distances
-    int sp;
+    uint32_t lo, top, lim;  // as in StackN; top: the next free reference row of this lane
+    private_u32* spill;     // kSpill references, then kSpill distances
     PTD void init(uint32_t* base, uint32_t* spill_words) {
-        lds = (lds_u32*)base;
+        lo = lds_addr(base);
+        top = lo;
+        lim = uint32_t(__builtin_amdgcn_readfirstlane(int(lo - 4u * (threadIdx.x & 63u)))) + uint32_t(ROWS) * kRowBytes;
         spill = (private_u32*)spill_words;
-        sp = 0;
     }
+    PTD void reset() { top = lo; }
+    PTD int over() const { return int((top - lo) / kRowBytes) - ROWS; }
     PTD void push(uint32_t v, float d) {
-        if (sp < ROWS) {
-            lds[sp * kBlock] = v;
-            lds[(sp + ROWS) * kBlock] = __float_as_uint(d);
+        if (top < lim) {
+            lds_ptr(top)[0] = v;
+            lds_ptr(top)[ROWS * kBlock] = __float_as_uint(d);
         } else {
-            spill[sp - ROWS] = v;
-            spill[sp - ROWS + kSpill] = __float_as_uint(d);
+            spill[over()] = v;
+            spill[over() + kSpill] = __float_as_uint(d);
         }
-        ++sp;
+        top += kRowBytes;
     }
     PTD void pop(uint32_t& v, float& d) {
-        --sp;
-        if (sp < ROWS) {
-            v = lds[sp * kBlock];
-            d = __uint_as_float(lds[(sp + ROWS) * kBlock]);
+        top -= kRowBytes;
+        if (top < lim) {
+            v = lds_ptr(top)[0];
+            d = __uint_as_float(lds_ptr(top)[ROWS * kBlock]);
         } else {
-            v = spill[sp - ROWS];
-            d = __uint_as_float(spill[sp - ROWS + kSpill]);
+            v = spill[over()];
+            d = __uint_as_float(spill[over() + kSpill]);
         }
     }
-    PTD bool empty() const { return sp == 0; }
+    PTD bool empty() const { return top == lo; }
 };
 
 // LDS rows of the ordered traversals' stacks (closest hit: references and entry distances, kDistRows each): 16 rows = 8 KB
@@ -280,7 +293,7 @@ PTD bool tri_hit(V3 p0, V3 e1, V3 e2, const V3& o, const V3& d, float min_dis, f
 // slots or only leaves are left), one 64-byte record per node: per slot the box as 16-bit
 // coordinates on a grid over the scene bounds (origin q_org, spacing q_step per axis), rounded outwards by at least one
 // grid step, and the reference of the slot's subtree:
-//      4 x {c.x, c.y, c.z, ref},   c.x = lo.x | hi.x << 16  etc.,  ref = kEmptyRef for an unused slot.
+//      4 x {c.x, c.y, c.z, ref},   c.x = lo.x | hi.x << 16  etc.,  for an unused slot a point box and the reference of an empty leaf (empty_slot_ref).
 // With the exact decisions gone from the interior nodes the traversal kernels are bound by the latency of the dependent
 // node fetches (a handful of waves per SIMD, each waiting for its next node), so the layout halves the number of
 // fetches on a ray's way down: 16 bytes per box instead of 24 + reference, two tree levels per fetch.
@@ -345,7 +358,7 @@ PTD bool cheap_go(const BoxC& b, float tmin, float far) {
     return b.tn <= b.tf && b.tn <= far && __fmaf_rn(kNearTie, fabsf(b.tn), b.tf) >= tmin;
 }
 
-constexpr uint32_t kEmptyRef = 0xffffffffu;  // unused slot of a 4-wide navigation node
+constexpr uint32_t kEmptyRef = 0xffffffffu;  // no navigation node (host side); unused slot of an 8-wide node
 
 // 8-wide navigation nodes (PT_NAV_WIDTH = 8), 80 bytes = 5 x uint4.  A node's slots are the result of opening the
 // interior slot with the largest surface until there are eight (or only leaves are left); their boxes are stored on an
@@ -408,7 +421,9 @@ PTD void nav_fetch(const DevScene& sc, const Treelet& tl, uint32_t cur, uint4& c
         c2 = make_uint4(c.x, c.y, c.z, c.w);
         c3 = make_uint4(d.x, d.y, d.z, d.w);
     } else {
-        const uint4* w = sc.qnodes + 4 * size_t(cur);
+        // a 32-bit byte offset from the (wave-uniform) array base: one shift instead of 64-bit address arithmetic per lane
+        // (the scene builder refuses trees with 2^26 navigation nodes or more)
+        const uint4* w = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.qnodes) + uint32_t(cur << 6));
         c0 = w[0];
         c1 = w[1];
         c2 = w[2];

@@ -164,7 +164,9 @@ struct ClosestLane {
     }
 
     // one navigation node: its (up to) four slots through the conservative test; the nearest one that can hold a candidate
-    // is visited next, the others are deferred in far-to-near order, each with its entry distance
+    // is visited next, the others are deferred in far-to-near order, each with its entry distance.  An unused slot is not
+    // tested for: it holds a box that is a single point and the reference of a leaf without triangles (empty_slot_ref in
+    // scene_dev.h), so the rare ray that passes through that point visits nothing.
     template <class C>
     PTD void inner(const DevScene& sc, const Treelet& tl, DistStack& st, C& wc) {
         wc.node();
@@ -178,10 +180,10 @@ struct ClosestLane {
             const float inf = __builtin_huge_valf(), far = cull_bound();
             const BoxC b0 = box_cheap(c0.x, c0.y, c0.z, cr), b1 = box_cheap(c1.x, c1.y, c1.z, cr);
             const BoxC b2 = box_cheap(c2.x, c2.y, c2.z, cr), b3 = box_cheap(c3.x, c3.y, c3.z, cr);
-            float k0 = (bool(c0.w != kEmptyRef) & cheap_go(b0, tmin, far)) ? b0.tn : inf;
-            float k1 = (bool(c1.w != kEmptyRef) & cheap_go(b1, tmin, far)) ? b1.tn : inf;
-            float k2 = (bool(c2.w != kEmptyRef) & cheap_go(b2, tmin, far)) ? b2.tn : inf;
-            float k3 = (bool(c3.w != kEmptyRef) & cheap_go(b3, tmin, far)) ? b3.tn : inf;
+            float k0 = cheap_go(b0, tmin, far) ? b0.tn : inf;
+            float k1 = cheap_go(b1, tmin, far) ? b1.tn : inf;
+            float k2 = cheap_go(b2, tmin, far) ? b2.tn : inf;
+            float k3 = cheap_go(b3, tmin, far) ? b3.tn : inf;
             uint32_t r0 = c0.w, r1 = c1.w, r2 = c2.w, r3 = c3.w;
             auto order = [](float& ka, uint32_t& ra, float& kb, uint32_t& rb) {  // afterwards ka <= kb
                 const bool sw = kb < ka;
@@ -352,10 +354,10 @@ struct AnyLane {
         {
             uint4 c0, c1, c2, c3;
             nav_fetch(sc, tl, cur, c0, c1, c2, c3);
-            const bool g0 = bool(c0.w != kEmptyRef) & cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), tmin, far_end);
-            const bool g1 = bool(c1.w != kEmptyRef) & cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), tmin, far_end);
-            const bool g2 = bool(c2.w != kEmptyRef) & cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), tmin, far_end);
-            const bool g3 = bool(c3.w != kEmptyRef) & cheap_go(box_cheap(c3.x, c3.y, c3.z, cr), tmin, far_end);
+            const bool g0 = cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), tmin, far_end);
+            const bool g1 = cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), tmin, far_end);
+            const bool g2 = cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), tmin, far_end);
+            const bool g3 = cheap_go(box_cheap(c3.x, c3.y, c3.z, cr), tmin, far_end);
             // the order does not change the answer; slots are listed larger subtree first, as the builder orders children for
             // exactly this query (src/bvh.cpp:137-144), so the first slot is visited first and the last one pushed first
             uint32_t nxt = kDone;
@@ -669,7 +671,7 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
                     L.idle();
                 } else {
                     L.begin(sc, ray, pre);
-                    st.sp = 0;
+                    st.reset();
                     state = kLaneBusy;
                     defer = false;
                 }
@@ -735,7 +737,7 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
                     L.idle();
                 } else {
                     L.begin(sc, ray, pre);
-                    st.sp = 0;
+                    st.reset();
                     state = kLaneBusy;
                     defer = false;
                 }

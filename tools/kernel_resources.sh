@@ -2,7 +2,7 @@
 # Scratch: registers, spills, LDS and occupancy of the traversal kernels as the compiler reports them.
 # Usage: tools/kernel_resources.sh [extra compiler flags...]
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -munsafe-fp-atomics -Wno-unused-function \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -munsafe-fp-atomics -Wno-unused-function \
     -Iinclude -Ibuild "$@" -Rpass-analysis=kernel-resource-usage -c -o /tmp/kr.o path-tracer_amd/csrc/pt_hip.hip > /tmp/kr.txt 2>&1
 python3 - <<'PY'
 import re
