@@ -386,7 +386,7 @@ struct GenerateIo {
                     const V3& d) const {
         emit(sc, shard, fin && !defer, j, h, c, o, d);
         const bool df = fin && defer;
-        if (__any(df)) {
+        if (wave_any(df)) {
             const uint32_t dl = wave_alloc(df, dq.count + shard);
             if (df) {
                 store_shared(&dq.e[size_t(shard) * kShard + dl].x, j);
@@ -459,7 +459,7 @@ struct ExtendIo {
             hq.h1[sbase + local] = make_float4(c.pix, c.meta, h.t, 0.0f);
         }
         const bool d = fin && defer;
-        if (__any(d)) {
+        if (wave_any(d)) {
             const uint32_t dl = wave_alloc(d, dq.count + shard);
             if (d) {
                 store_shared(&dq.e[sbase + dl].x, j);
@@ -541,7 +541,7 @@ struct ShadowIo {
             lbuf[c.slot] = L;
         }
         const bool d = fin && defer;
-        if (__any(d)) {
+        if (wave_any(d)) {
             const uint32_t dl = wave_alloc(d, dq.count + shard);
             if (d) store_shared(&dq.e[sbase + dl].x, j);
         }

@@ -354,8 +354,11 @@ PTD BoxC box_cheap(uint32_t cx, uint32_t cy, uint32_t cz, const CheapRay& r) {
 // before the far bound; it leaves the box after its near end, with a margin of kNearTie on the scale of the entry
 // distance (for a box that ends behind the ray's origin the entry is the larger of its two distances, the scale of the
 // rounding errors of the triangle distances inside the box).
+// As one comparison: the later of "enters the box" and "near end, less the margin" against the earlier of "leaves the
+// box" and "far bound" (the near end never lies beyond the far bound, so measuring it against the far bound as well
+// changes nothing).
 PTD bool cheap_go(const BoxC& b, float tmin, float far) {
-    return b.tn <= b.tf && b.tn <= far && __fmaf_rn(kNearTie, fabsf(b.tn), b.tf) >= tmin;
+    return fmaxf(b.tn, __fmaf_rn(-kNearTie, fabsf(b.tn), tmin)) <= fminf(b.tf, far);
 }
 
 constexpr uint32_t kEmptyRef = 0xffffffffu;  // no navigation node (host side); unused slot of an 8-wide node

@@ -34,10 +34,14 @@ constexpr uint32_t kMinBoxLanes = PT_MIN_BOX_LANES;  // leave the box phase for 
 constexpr float kDeferExact = -1.0f;
 
 PTD uint32_t lane_id() { return __lane_id(); }
+// Ballots straight from the condition (the runtime's __ballot / __any take an int: a select and a compare per call).
+PTD uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+PTD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+PTD uint32_t wave_count(bool p) { return uint32_t(__builtin_popcountll(__builtin_amdgcn_ballot_w64(p))); }
 
 // Wave-level queue allocation: one atomic per wave, ballot + prefix popcount for the lane offset.
 PTD uint32_t wave_alloc(bool want, uint32_t* counter) {
-    const uint64_t mask = __ballot(want);
+    const uint64_t mask = wave_ballot(want);
     const uint32_t total = uint32_t(__popcll(mask));
     uint32_t base = 0;
     if (total != 0u) {
@@ -607,7 +611,7 @@ constexpr int kLaneEmpty = 0, kLaneBusy = 1, kLaneDone = 2;
 // Takes `want` lanes' next queue positions from the shard's fetch counter.  Returns the position (valid when < count) and
 // clears `more` once the counter has passed the end of the queue.
 PTD uint32_t wave_fetch(bool want, uint32_t* counter, uint32_t count, bool& more) {
-    const uint64_t mask = __ballot(want);
+    const uint64_t mask = wave_ballot(want);
     const uint32_t n = uint32_t(__popcll(mask));
     uint32_t base = 0;
     if (n != 0u) {
@@ -646,7 +650,7 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
     for (;;) {
         const bool walked = state == kLaneBusy && L.finished();
         const bool fin = walked || state == kLaneDone;
-        if (__any(fin)) {
+        if (wave_any(fin)) {
             ps.round(fin);
             if (walked) defer = L.settle(sc, bound, wc);
             io.commit(sc, shard, fin, j, L.hit, defer, bound, carry, L.org(), L.dir());
@@ -677,23 +681,23 @@ PTD void closest_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetc
                 }
             }
         }
-        if (!__any(state == kLaneBusy)) {
-            if (more || __any(state == kLaneDone)) continue;
+        if (!wave_any(state == kLaneBusy)) {
+            if (more || wave_any(state == kLaneDone)) continue;
             break;
         }
         const uint32_t low = more ? kRefillBelow : 1u;
         for (;;) {
             for (;;) {
-                const bool inner = state == kLaneBusy && L.box_ready();
-                const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
+                const bool inner = L.box_ready();  // only a busy lane has a node to visit: the others hold kDone
+                const uint32_t n_inner = wave_count(inner);
                 if (n_inner == 0u) break;
                 ps.box(n_inner);
                 if (inner) L.inner(sc, tl, st, wc);
                 if (n_inner < kMinBoxLanes) break;
             }
-            if constexpr (!Lane::kReferenceOrder) ps.leaf(state == kLaneBusy && L.leaf_ready(), L.cur);
-            if (state == kLaneBusy && L.leaf_ready()) L.leaf(sc, st, wc);
-            if (uint32_t(__popcll(__ballot(state == kLaneBusy && !L.finished()))) < low) break;
+            if constexpr (!Lane::kReferenceOrder) ps.leaf(L.leaf_ready(), L.cur);
+            if (L.leaf_ready()) L.leaf(sc, st, wc);
+            if (wave_count(!L.finished()) < low) break;
         }
     }
     ps.flush(Io::kPhaseClass);
@@ -717,7 +721,7 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
     for (;;) {
         const bool walked = state == kLaneBusy && L.finished();
         const bool fin = walked || state == kLaneDone;
-        if (__any(fin)) {
+        if (wave_any(fin)) {
             ps.round(fin);
             if (walked) defer = L.settle(sc, wc);
             io.commit(sc, shard, fin, j, L.occluded, defer, carry);
@@ -743,23 +747,23 @@ PTD void any_wave(const DevScene& sc, Io& io, uint32_t shard, uint32_t* fetch, u
                 }
             }
         }
-        if (!__any(state == kLaneBusy)) {
-            if (more || __any(state == kLaneDone)) continue;
+        if (!wave_any(state == kLaneBusy)) {
+            if (more || wave_any(state == kLaneDone)) continue;
             break;
         }
         const uint32_t low = more ? kRefillBelow : 1u;
         for (;;) {
             for (;;) {
-                const bool inner = state == kLaneBusy && L.box_ready();
-                const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
+                const bool inner = L.box_ready();  // only a busy lane has a node to visit: the others hold kDone
+                const uint32_t n_inner = wave_count(inner);
                 if (n_inner == 0u) break;
                 ps.box(n_inner);
                 if (inner) L.inner(sc, tl, st, wc);
                 if (n_inner < kMinBoxLanes) break;
             }
-            if constexpr (!Lane::kReferenceOrder) ps.leaf(state == kLaneBusy && L.leaf_ready(), L.cur);
-            if (state == kLaneBusy && L.leaf_ready()) L.leaf(sc, st, wc);
-            if (uint32_t(__popcll(__ballot(state == kLaneBusy && !L.finished()))) < low) break;
+            if constexpr (!Lane::kReferenceOrder) ps.leaf(L.leaf_ready(), L.cur);
+            if (L.leaf_ready()) L.leaf(sc, st, wc);
+            if (wave_count(!L.finished()) < low) break;
         }
     }
     ps.flush(Io::kPhaseClass);
