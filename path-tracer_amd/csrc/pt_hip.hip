@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <queue>
@@ -411,19 +412,98 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
     auto headless = [&](uint32_t i) { return i != 0u && fat[parent[i]] && i == d->nodes[parent[i]].first + 1u; };
 
     // ---- navigation tree of the ordered traversal: which binary nodes become navigation nodes, and their numbers.
-    // Collapse: the navigation node of binary interior node N starts from N's two children and opens, one at a time,
-    // the interior slot with the largest surface (the box a ray is most likely to enter anyway) until it has kWide
-    // slots or only leaves and fat leaves are left; slots stay in the binary tree's left-to-right order.  The
-    // interior slots are navigation nodes in turn.  (Against taking N's grandchildren: 0.4 - 2 % more rays per second;
-    // the sweep builder's trees are balanced enough that the two rarely differ.)
+    // The navigation node of binary interior node N holds up to kWide slots: N's two children, some of them opened into
+    // their own children in turn; slots stay in the binary tree's left-to-right order, and the interior slots are
+    // navigation nodes themselves.
     auto leaf_like = [&](uint32_t c) { return d->nodes[c].count != 0u || fat[c]; };
     auto surface = [&](uint32_t c) {
         const pt_bvh_node& b = d->nodes[c];
         const double x = double(b.hi[0]) - double(b.lo[0]), y = double(b.hi[1]) - double(b.lo[1]), z = double(b.hi[2]) - double(b.lo[2]);
         return x * y + y * z + z * x;
     };
+    // Which slots a navigation node gets.  Default: the choice that minimises the expected number of navigation nodes a
+    // random ray visits, sum of surface(N) over the navigation nodes N (a ray that meets the scene meets a box with a
+    // probability proportional to its surface).  F(n, i) = that sum for the subtree of binary node n when n may take up
+    // to i slots of the node above it: 0 for a leaf or fat leaf; otherwise either n is one slot and a navigation node
+    // itself, surface(n) + G(n, kWide), or it is opened and its children share the i slots, G(n, i) = the best split
+    // F(left, a) + F(right, i - a).  Filled bottom-up; `share[n][i]` keeps the left child's part (0: n stays one slot).
+    // PT_COLLAPSE=greedy in the environment selects the earlier rule instead: open the interior slot with the largest
+    // surface until the node is full.
+    const char* collapse_env = std::getenv("PT_COLLAPSE");
+    const bool greedy = collapse_env && std::strcmp(collapse_env, "greedy") == 0;
+    bool forward = true;  // every child index exceeds its parent's, as in every tree a top-down builder emits
+    for (uint32_t i = 0; i < d->n_nodes && forward; ++i)
+        if (d->nodes[i].count == 0u && d->nodes[i].first <= i) forward = false;
+    std::vector<float> cost;     // F(n, 1..kWide)
+    std::vector<uint8_t> share;  // share[n][i], i = 2..kWide, and share[n][1] = the left child's part when n is a navigation node
+    if (!greedy) {
+        cost.assign(size_t(d->n_nodes) * kWide, 0.0f);
+        share.assign(size_t(d->n_nodes) * kWide, 0);
+        std::vector<uint32_t> bottom_up;
+        if (!forward) {  // children before parents
+            std::vector<uint32_t> stack{0u};
+            while (!stack.empty()) {
+                const uint32_t n = stack.back();
+                stack.pop_back();
+                bottom_up.push_back(n);
+                if (d->nodes[n].count == 0u) {
+                    stack.push_back(d->nodes[n].first);
+                    stack.push_back(d->nodes[n].first + 1u);
+                }
+            }
+            std::reverse(bottom_up.begin(), bottom_up.end());
+        }
+        for (uint32_t k = 0; k < d->n_nodes; ++k) {
+            const uint32_t n = forward ? d->n_nodes - 1u - k : bottom_up[k];
+            if (leaf_like(n)) continue;  // all zero
+            const float* fl = &cost[size_t(d->nodes[n].first) * kWide];
+            const float* fr = fl + kWide;
+            float g[kWide + 1];
+            uint8_t ga[kWide + 1];
+            for (int j = 2; j <= kWide; ++j) {
+                g[j] = std::numeric_limits<float>::infinity();
+                ga[j] = 1;
+                for (int a = 1; a < j; ++a) {
+                    const float c = fl[a - 1] + fr[j - a - 1];
+                    if (c < g[j]) {
+                        g[j] = c;
+                        ga[j] = uint8_t(a);
+                    }
+                }
+            }
+            float* f = &cost[size_t(n) * kWide];
+            uint8_t* sh = &share[size_t(n) * kWide];
+            f[0] = float(surface(n)) + g[kWide];
+            sh[0] = ga[kWide];
+            for (int i = 2; i <= kWide; ++i) {
+                const bool opened = g[i] < f[0];
+                f[i - 1] = opened ? g[i] : f[0];
+                sh[i - 1] = opened ? ga[i] : 0;
+            }
+        }
+        clk.lap("collapse costs");
+    }
     auto collapse = [&](uint32_t n, uint32_t* slots) -> int {
         int ns = 0;
+        if (!greedy) {
+            // (binary node, slots it may take), left to right
+            std::pair<uint32_t, int> todo[2 * kWide];
+            int nt = 0;
+            const int left = share[size_t(n) * kWide];
+            todo[nt++] = {d->nodes[n].first + 1u, kWide - left};
+            todo[nt++] = {d->nodes[n].first, left};
+            while (nt > 0) {
+                const auto [m, j] = todo[--nt];
+                const int a = (j >= 2 && !leaf_like(m)) ? share[size_t(m) * kWide + size_t(j - 1)] : 0;
+                if (a == 0) {
+                    slots[ns++] = m;
+                } else {
+                    todo[nt++] = {d->nodes[m].first + 1u, j - a};
+                    todo[nt++] = {d->nodes[m].first, a};
+                }
+            }
+            return ns;
+        }
         slots[ns++] = d->nodes[n].first;
         slots[ns++] = d->nodes[n].first + 1u;
         while (ns < kWide) {
@@ -460,9 +540,6 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
         // Numbered in the order of their binary node index (the reference's numbering keeps a subtree contiguous) when every
         // child index exceeds its parent's, as in every tree a top-down builder emits -- one streaming pass; otherwise
         // depth-first.  Leaf records in the order of the binary nodes.
-        bool forward = true;
-        for (uint32_t i = 0; i < d->n_nodes && forward; ++i)
-            if (d->nodes[i].count == 0u && d->nodes[i].first <= i) forward = false;
         if (forward) {
             std::vector<uint8_t> is_nav(d->n_nodes, 0);
             if (!leaf_like(0u)) is_nav[0] = 1;
