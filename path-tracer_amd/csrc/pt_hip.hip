@@ -738,13 +738,20 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
             org[a] = dev.q_org[a];
             step[a] = dev.q_step[a];
         }
-        auto q_lo = [&](float v, int a) -> uint32_t {  // largest grid point at or below v, minus one step of safety
-            const double g = std::floor((double(v) - org[a]) / step[a]) - 1.0;
-            return uint32_t(std::min(65535.0, std::max(0.0, g)));
+        // The grid planes that enclose a box most tightly: the largest grid point at or below its lower face, the smallest
+        // at or above its upper face (checked in extended precision, where org + g * step is exact for these magnitudes).
+        // The device never forms a plane's position: its distance estimates carry their own padding (box_cheap).
+        // PT_GRID_SAFETY=1 in the environment adds one grid step on either side, as earlier versions did.
+        const double safety = (std::getenv("PT_GRID_SAFETY") && std::atoi(std::getenv("PT_GRID_SAFETY")) != 0) ? 1.0 : 0.0;
+        auto q_lo = [&](float v, int a) -> uint32_t {
+            double g = std::floor((double(v) - org[a]) / step[a]);
+            while ((long double)(org[a]) + (long double)(g) * (long double)(step[a]) > (long double)(v)) g -= 1.0;
+            return uint32_t(std::min(65535.0, std::max(0.0, g - safety)));
         };
-        auto q_hi = [&](float v, int a) -> uint32_t {  // smallest grid point at or above v, plus one step of safety
-            const double g = std::ceil((double(v) - org[a]) / step[a]) + 1.0;
-            return uint32_t(std::min(65535.0, std::max(0.0, g)));
+        auto q_hi = [&](float v, int a) -> uint32_t {
+            double g = std::ceil((double(v) - org[a]) / step[a]);
+            while ((long double)(org[a]) + (long double)(g) * (long double)(step[a]) < (long double)(v)) g += 1.0;
+            return uint32_t(std::min(65535.0, std::max(0.0, g + safety)));
         };
         auto leaf_ref = [&](uint32_t ni) -> uint32_t {  // of a leaf or fat leaf
             const pt_bvh_node& b = d->nodes[ni];
