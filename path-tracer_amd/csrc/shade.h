@@ -83,10 +83,10 @@ PTD void complete(const TriRec& t, float u, float v, Surf& o) {
     const V3 v0 = t.v0(), v1 = t.v1(), v2 = t.v2();
     o.p = v0 * b0 + v1 * b1 + v2 * b2;
     const V3 g = cross(v0 - v2, v1 - v2);
-    V3 n = g;
-    if (t.flags() & kTriHasNormals) n = t.n0() * b0 + t.n1() * b1 + t.n2() * b2;
-    o.n = normalized(n);
     o.ng = normalized(g);
+    // without vertex normals the shading normal is the geometric one: the same vector normalised once, not twice
+    o.n = o.ng;
+    if (t.flags() & kTriHasNormals) o.n = normalized(t.n0() * b0 + t.n1() * b1 + t.n2() * b2);
     o.ts = Frame(o.n);
 }
 

@@ -16,4 +16,4 @@ import os
 if os.environ.get('PT_COUNT'):
     film, st = g.render(0, min(total, 64), traversal=1, samples_per_pass=64, flags=api.FLAG_COUNT_WORK)
     un = {'generate': st['paths'], 'extend': st['closest_rays'] - st['paths'], 'shadow': st['any_rays']}
-    print({k: (round(st['nodes_fetched'][k] / un[k], 2), round(st['nodes_from_lds'][k] / un[k], 2), round(st['tris_fetched'][k] / un[k], 2)) for k in un}, flush=True)
+    print({k: (round(st['nodes_fetched'][k] / un[k], 2), round(st['nodes_from_lds'][k] / un[k], 2), round(st['tris_fetched'][k] / un[k], 2)) for k in un}, 'retraced', st['exact_retraces'], 'of', st['closest_rays'] + st['any_rays'], flush=True)
