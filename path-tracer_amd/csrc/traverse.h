@@ -54,7 +54,7 @@ struct StackN {
     static constexpr int kRows = ROWS;            // entries per lane in LDS
     static constexpr int kSpill = kMaxStack - ROWS;  // further entries per lane in scratch
     uint32_t lo;         // address of &shared[0][threadIdx.x]
-    uint32_t top;        // address of the next free entry, &shared[depth][threadIdx.x], also beyond the LDS rows (then only a number)
+    uint32_t top;        // address of &shared[sp][threadIdx.x], also beyond the LDS rows (then only a number)
     uint32_t lim;        // wave-uniform: address of the wave's first word of row ROWS
     private_u32* spill;  // kSpill private words, declared by the function that owns the stack (kept out of this
                          // struct so that the compiler keeps everything but the array itself in registers)
