@@ -743,15 +743,21 @@ int build_scene(pt_hip_scene* s, const pt_scene_desc* d) {
         // The device never forms a plane's position: its distance estimates carry their own padding (box_cheap).
         // PT_GRID_SAFETY=1 in the environment adds one grid step on either side, as earlier versions did.
         const double safety = (std::getenv("PT_GRID_SAFETY") && std::atoi(std::getenv("PT_GRID_SAFETY")) != 0) ? 1.0 : 0.0;
+        // (clamped to the grid before the check, so that a face that is not finite ends at the grid's end instead of in a loop)
+        auto plane = [&](double g, int a) { return (long double)(org[a]) + (long double)(g) * (long double)(step[a]); };
         auto q_lo = [&](float v, int a) -> uint32_t {
             double g = std::floor((double(v) - org[a]) / step[a]);
-            while ((long double)(org[a]) + (long double)(g) * (long double)(step[a]) > (long double)(v)) g -= 1.0;
-            return uint32_t(std::min(65535.0, std::max(0.0, g - safety)));
+            if (!(g >= 0.0)) g = 0.0;
+            if (g > 65535.0) g = 65535.0;
+            for (int k = 0; k < 2 && g > 0.0 && plane(g, a) > (long double)(v); ++k) g -= 1.0;
+            return uint32_t(std::max(0.0, g - safety));
         };
         auto q_hi = [&](float v, int a) -> uint32_t {
             double g = std::ceil((double(v) - org[a]) / step[a]);
-            while ((long double)(org[a]) + (long double)(g) * (long double)(step[a]) < (long double)(v)) g += 1.0;
-            return uint32_t(std::min(65535.0, std::max(0.0, g + safety)));
+            if (!(g <= 65535.0)) g = 65535.0;
+            if (g < 0.0) g = 0.0;
+            for (int k = 0; k < 2 && g < 65535.0 && plane(g, a) < (long double)(v); ++k) g += 1.0;
+            return uint32_t(std::min(65535.0, g + safety));
         };
         auto leaf_ref = [&](uint32_t ni) -> uint32_t {  // of a leaf or fat leaf
             const pt_bvh_node& b = d->nodes[ni];
