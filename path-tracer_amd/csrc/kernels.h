@@ -1001,7 +1001,8 @@ __global__ void k_dense_counts(const uint32_t* total, uint32_t* path_count, uint
 // pixel of the 20x20 patch gathers its up to 4x4 contributing samples into registers: no atomics in the loop, and a
 // fixed summation order inside the region.  The patch is added to the film once at the end.
 constexpr int kFilmRec = 20;     // floats per published sample: wy[4], wx[4], r*wx[4], g*wx[4], b*wx[4]
-constexpr int kFilmStride = 21;  // odd record stride: neighbouring samples fall into different LDS banks
+constexpr int kFilmStride = 21;  // odd record stride: neighbouring samples fall into different LDS banks (16-byte records read
+                                 // with ds_read_b128 measured the same: the kernel moves LDS bytes, it is not short of issue slots)
 
 __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const float4* lbuf, float* film) {
     __shared__ float s_rec[256 * kFilmStride];
@@ -1021,6 +1022,12 @@ __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const fl
     const int bx = int(px & ~31u), by = int(py & ~31u);
     const float bw = float(min(32, int(sc.cam.width) - bx)), bh = float(min(32, int(sc.cam.height) - by));
     float* my = s_rec + (syp * 16 + sxp) * kFilmStride;
+    // what does not change from one sample number to the next: the pixel's Sobol' words, and the filter table in LDS (the
+    // table is indexed per lane; as part of the kernel's arguments it was a memory gather per weight)
+    __shared__ float s_filter[33];
+    if (threadIdx.x < 33u) s_filter[threadIdx.x] = sc.filter[threadIdx.x];
+    const uint2 xy = inside ? pixel_words(sc, px, py) : make_uint2(0u, 0u);
+    __syncthreads();
 
     // the (up to) two patch pixels this thread accumulates: q0 = tid, q1 = tid + 256 (< 400)
     float acc[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
@@ -1030,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const fl
 #pragma unroll
         for (int k = 0; k < kFilmRec; ++k) rec[k] = 0.0f;
         if (inside) {
-            const V2 j = pixel_jitter(sc, pa.frame_tab + size_t(s) * 1024u, px, py);
+            const V2 j = pixel_jitter(sc, pa.frame_tab + size_t(s) * 1024u, xy, px, py);
             const float qx = (float(int(px)) + j.x) - float(bx), qy = (float(int(py)) + j.y) - float(by);
             // ImageBlock::put drops a sample whose rounded position leaves its block (src/block.cpp:67-71); that happens
             // when pixel + jitter rounds up to the next integer in the last column or row of a block
@@ -1043,8 +1050,8 @@ __global__ __launch_bounds__(256) void k_film(DevScene sc, PassArgs pa, const fl
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int x = cx + k, y = cy + k;
-                    const float wx = (x >= x0 && x <= x1) ? sc.filter[min(int(fabsf(float(x) - lx) * 16.0f), 32)] : 0.0f;
-                    const float wy = (y >= y0 && y <= y1) ? sc.filter[min(int(fabsf(float(y) - ly) * 16.0f), 32)] : 0.0f;
+                    const float wx = (x >= x0 && x <= x1) ? s_filter[min(int(fabsf(float(x) - lx) * 16.0f), 32)] : 0.0f;
+                    const float wy = (y >= y0 && y <= y1) ? s_filter[min(int(fabsf(float(y) - ly) * 16.0f), 32)] : 0.0f;
                     rec[k] = wy;
                     rec[4 + k] = wx;
                     rec[8 + k] = L.x * wx;

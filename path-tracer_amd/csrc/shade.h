@@ -495,14 +495,21 @@ struct Sampler {
 };
 
 // samplePixel2D (src/sampler.cpp:116-123): dimensions 0 and 1, remapped to the pixel
-PTD V2 pixel_jitter(const DevScene& sc, const uint32_t* frame_row, uint32_t px, uint32_t py) {
-    const uint2 f = *reinterpret_cast<const uint2*>(frame_row);
+// the pixel's share of the first two Sobol' words: X[px] ^ Y[py] (the same for every sample number)
+PTD uint2 pixel_words(const DevScene& sc, uint32_t px, uint32_t py) {
     const uint2 x = *reinterpret_cast<const uint2*>(sc.sob_x + size_t(px) * 1024u);
     const uint2 y = *reinterpret_cast<const uint2*>(sc.sob_y + size_t(py) * 1024u);
-    V2 u{sobol_to_float(f.x ^ x.x ^ y.x), sobol_to_float(f.y ^ x.y ^ y.y)};
+    return make_uint2(x.x ^ y.x, x.y ^ y.y);
+}
+PTD V2 pixel_jitter(const DevScene& sc, const uint32_t* frame_row, uint2 xy, uint32_t px, uint32_t py) {
+    const uint2 f = *reinterpret_cast<const uint2*>(frame_row);
+    V2 u{sobol_to_float(f.x ^ xy.x), sobol_to_float(f.y ^ xy.y)};
     u.x = std_clamp(u.x * float(int(sc.sob_scale)) - float(int(px)), 0.0f, kOneMinusEps);
     u.y = std_clamp(u.y * float(int(sc.sob_scale)) - float(int(py)), 0.0f, kOneMinusEps);
     return u;
+}
+PTD V2 pixel_jitter(const DevScene& sc, const uint32_t* frame_row, uint32_t px, uint32_t py) {
+    return pixel_jitter(sc, frame_row, pixel_words(sc, px, py), px, py);
 }
 
 }  // namespace ptd
