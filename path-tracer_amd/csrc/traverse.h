@@ -316,38 +316,55 @@ constexpr float kCheapPad = 0x1p-20f;
 #endif
 constexpr float kNearTie = 1.0f / float(1u << PT_NEAR_TIE_LOG2);
 
-// per-ray constants of box_cheap
+// per-ray constants of box_cheap.  Which of a slot's two planes on an axis the ray meets first is decided by the sign of
+// the direction alone (lo <= hi on the grid, and the padding below keeps that order), so instead of a minimum and a
+// maximum per axis and slot -- half-rate instructions on this chip, like the conversions -- the two 16-bit halves of the
+// plane word are swapped for a negative direction (one rotate by `swap` = 0 or 16 bits): the entry distance then always
+// comes from the low half, the exit distance from the high half.  The values are the ones min / max would have picked.
 struct CheapRay {
-    V3 a;      // q_step / d
-    V3 b_lo;   // addend of the lo planes
-    V3 b_hi;   // addend of the hi planes
+    V3 a;       // q_step / d
+    V3 b_in;    // addend of the plane the ray meets first:  (q_org - o) / d - pad
+    V3 b_out;   // addend of the other plane:                (q_org - o) / d + pad
     PTD void set(const DevScene& sc, const RayPre& p) {
         const V3 org{sc.q_org[0], sc.q_org[1], sc.q_org[2]}, step{sc.q_step[0], sc.q_step[1], sc.q_step[2]};
         a = V3{step.x * p.y.x, step.y * p.y.y, step.z * p.y.z};
         const V3 rel = org - p.o;
         const V3 c{rel.x * p.y.x, rel.y * p.y.y, rel.z * p.y.z};
-        // d > 0: the lo plane is met first; d < 0: the hi plane
-        const V3 e{copysignf(kCheapPad * (fabsf(c.x) + 65535.0f * fabsf(a.x)), p.d.x), copysignf(kCheapPad * (fabsf(c.y) + 65535.0f * fabsf(a.y)), p.d.y),
-                   copysignf(kCheapPad * (fabsf(c.z) + 65535.0f * fabsf(a.z)), p.d.z)};
-        b_lo = c - e;
-        b_hi = c + e;
+        const V3 e{kCheapPad * (fabsf(c.x) + 65535.0f * fabsf(a.x)), kCheapPad * (fabsf(c.y) + 65535.0f * fabsf(a.y)),
+                   kCheapPad * (fabsf(c.z) + 65535.0f * fabsf(a.z))};
+        b_in = c - e;
+        b_out = c + e;
     }
+    // rotate amounts that bring the first-met plane into the low half: 16 for a negative direction
+    PTD uint32_t swap_x() const { return (as_u(a.x) >> 31) << 4; }
+    PTD uint32_t swap_y() const { return (as_u(a.y) >> 31) << 4; }
+    PTD uint32_t swap_z() const { return (as_u(a.z) >> 31) << 4; }
 };
 
 struct BoxC {
     float tn, tf;  // entry and exit distance over all three (widened) slabs
 };
 
+// the swaps of a ray, once per node
+struct PlaneSwap {
+    uint32_t x, y, z;
+    PTD explicit PlaneSwap(const CheapRay& r) : x(r.swap_x()), y(r.swap_y()), z(r.swap_z()) {}
+};
+
 // cx, cy, cz: the three plane words of one child (lo in the low half, hi in the high half)
-PTD BoxC box_cheap(uint32_t cx, uint32_t cy, uint32_t cz, const CheapRay& r) {
-    const float x0 = __fmaf_rn(float(cx & 0xffffu), r.a.x, r.b_lo.x), x1 = __fmaf_rn(float(cx >> 16), r.a.x, r.b_hi.x);
-    const float y0 = __fmaf_rn(float(cy & 0xffffu), r.a.y, r.b_lo.y), y1 = __fmaf_rn(float(cy >> 16), r.a.y, r.b_hi.y);
-    const float z0 = __fmaf_rn(float(cz & 0xffffu), r.a.z, r.b_lo.z), z1 = __fmaf_rn(float(cz >> 16), r.a.z, r.b_hi.z);
+PTD BoxC box_cheap(uint32_t cx, uint32_t cy, uint32_t cz, const CheapRay& r, const PlaneSwap& sw) {
+    cx = __builtin_amdgcn_alignbit(cx, cx, sw.x);
+    cy = __builtin_amdgcn_alignbit(cy, cy, sw.y);
+    cz = __builtin_amdgcn_alignbit(cz, cz, sw.z);
+    const float x0 = __fmaf_rn(float(cx & 0xffffu), r.a.x, r.b_in.x), x1 = __fmaf_rn(float(cx >> 16), r.a.x, r.b_out.x);
+    const float y0 = __fmaf_rn(float(cy & 0xffffu), r.a.y, r.b_in.y), y1 = __fmaf_rn(float(cy >> 16), r.a.y, r.b_out.y);
+    const float z0 = __fmaf_rn(float(cz & 0xffffu), r.a.z, r.b_in.z), z1 = __fmaf_rn(float(cz >> 16), r.a.z, r.b_out.z);
     BoxC b;
-    b.tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-    b.tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    b.tn = fmaxf(fmaxf(x0, y0), z0);
+    b.tf = fminf(fminf(x1, y1), z1);
     return b;
 }
+PTD BoxC box_cheap(uint32_t cx, uint32_t cy, uint32_t cz, const CheapRay& r) { return box_cheap(cx, cy, cz, r, PlaneSwap(r)); }
 
 // Can the subtree of a box with estimates b hold a triangle that is accepted in [tmin, far]?  `far` is the far bound
 // already widened by the caller (near-tie window).  Three conditions: the (widened) slabs overlap; the ray enters the box

@@ -182,8 +182,9 @@ struct ClosestLane {
             uint4 c0, c1, c2, c3;
             nav_fetch(sc, tl, cur, c0, c1, c2, c3);
             const float inf = __builtin_huge_valf(), far = cull_bound();
-            const BoxC b0 = box_cheap(c0.x, c0.y, c0.z, cr), b1 = box_cheap(c1.x, c1.y, c1.z, cr);
-            const BoxC b2 = box_cheap(c2.x, c2.y, c2.z, cr), b3 = box_cheap(c3.x, c3.y, c3.z, cr);
+            const PlaneSwap sw(cr);
+            const BoxC b0 = box_cheap(c0.x, c0.y, c0.z, cr, sw), b1 = box_cheap(c1.x, c1.y, c1.z, cr, sw);
+            const BoxC b2 = box_cheap(c2.x, c2.y, c2.z, cr, sw), b3 = box_cheap(c3.x, c3.y, c3.z, cr, sw);
             float k0 = cheap_go(b0, tmin, far) ? b0.tn : inf;
             float k1 = cheap_go(b1, tmin, far) ? b1.tn : inf;
             float k2 = cheap_go(b2, tmin, far) ? b2.tn : inf;
@@ -358,10 +359,11 @@ struct AnyLane {
         {
             uint4 c0, c1, c2, c3;
             nav_fetch(sc, tl, cur, c0, c1, c2, c3);
-            const bool g0 = cheap_go(box_cheap(c0.x, c0.y, c0.z, cr), tmin, far_end);
-            const bool g1 = cheap_go(box_cheap(c1.x, c1.y, c1.z, cr), tmin, far_end);
-            const bool g2 = cheap_go(box_cheap(c2.x, c2.y, c2.z, cr), tmin, far_end);
-            const bool g3 = cheap_go(box_cheap(c3.x, c3.y, c3.z, cr), tmin, far_end);
+            const PlaneSwap sw(cr);
+            const bool g0 = cheap_go(box_cheap(c0.x, c0.y, c0.z, cr, sw), tmin, far_end);
+            const bool g1 = cheap_go(box_cheap(c1.x, c1.y, c1.z, cr, sw), tmin, far_end);
+            const bool g2 = cheap_go(box_cheap(c2.x, c2.y, c2.z, cr, sw), tmin, far_end);
+            const bool g3 = cheap_go(box_cheap(c3.x, c3.y, c3.z, cr, sw), tmin, far_end);
             // the order does not change the answer; slots are listed larger subtree first, as the builder orders children for
             // exactly this query (src/bvh.cpp:137-144), so the first slot is visited first and the last one pushed first
             uint32_t nxt = kDone;
