@@ -24,6 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd", "python"))
 
 import numpy as np  # noqa: E402
 
+VALU_MIX_RATE = 0.25    # wave64 vector instructions per SIMD cycle a traversal kernel's instruction mix can issue at (tools/valu_roof.hip)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 # What binds the traversal kernels is the rate at which a CU serves per-lane loads of DIFFERENT addresses: about one lane
 # and 16 bytes per clock, whichever cache level answers (tools/gather_roof.hip: dependent chains of 64-byte records at 6
@@ -296,6 +297,12 @@ def main():
         launch_s = kms[dominant] / max(kn[dominant], 1) * 1e-3
         traffic = counters.get("bytes_per_launch")
         valu, lanes = counters.get("valu_issue_frac"), counters.get("lanes_per_valu_inst_frac")
+        # Vector instructions per SIMD cycle of this run: the committed counter pass's figure (instructions x 2 / SIMD cycles)
+        # scaled by the launch time measured here (same kernel, same instructions).  What a SIMD can take: tools/valu_roof.hip.
+        valu_rate = None
+        if valu and counters.get("avg_launch_ms") and kn[dominant]:
+            valu_rate = valu / 2.0 * counters["avg_launch_ms"] / (kms[dominant] / kn[dominant])
+        valu_bound = gather_bound and valu_rate is not None and valu_rate / VALU_MIX_RATE >= achieved_gather / peak_gather
         out = {
             "metric": "Mrays/s", "value": rays_total / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
@@ -320,18 +327,30 @@ def main():
             # could take.  achieved = 16-byte lane accesses the kernel's queries need (counted by an instrumented pass) per
             # second of kernel time; peak = the measured rate of a chain of dependent 64-byte gathers from an L2-resident table
             # x 256 CUs; frac = achieved / peak.  The contract's HBM view of the same kernel is under "hbm".
-            "roofline": {"bound": "l1-gather" if gather_bound else "hbm",
-                         "bound_note": ("per-lane gathers of different addresses: the CU's address/data path takes one lane x 16 B per clock "
-                                        "(tools/gather_roof.hip); HBM, L2 and VALU roofs are not near") if gather_bound else
+            "roofline": {"bound": "valu-issue" if valu_bound else ("l1-gather" if gather_bound else "hbm"),
+                         "bound_note": ("vector instruction issue: the SIMDs issue this kernel's instructions at the rate its mix allows "
+                                        "(multiply-adds, adds, moves and bit operations 2.5-3.3 cycles per wave64 instruction, conversions, min / max, "
+                                        "compares, selects and three-operand integer instructions 4.4-5: tools/valu_roof.hip); its time follows its "
+                                        "instruction count, one for one, and not its loads -- the gather rate under 'gather' is the second limit") if valu_bound else
+                                       ("per-lane gathers of different addresses: the CU's address/data path takes one lane x 16 B per clock "
+                                        "(tools/gather_roof.hip)") if gather_bound else
                                        ("queues streamed once per bounce plus one gathered 128-byte record per hit; algorithmic bytes count what "
                                         "the caches serve too, the measured share of the HBM peak is hbm.measured_frac"),
                          "kernel": "k_" + dominant,
-                         "achieved": achieved_gather if gather_bound else (hbm_measured if hbm_measured is not None else achieved_hbm),
-                         "achieved_is": "counted lane accesses / kernel time" if gather_bound else
-                                        ("measured fabric bytes / kernel time (committed counter pass)" if hbm_measured is not None else "algorithmic bytes / kernel time"),
-                         "peak": peak_gather if gather_bound else HBM_PEAK_GBS,
-                         "unit": "G lane-accesses/s (16 B each)" if gather_bound else "GB/s",
-                         "frac": achieved_gather / peak_gather if gather_bound else (hbm_measured if hbm_measured is not None else achieved_hbm) / HBM_PEAK_GBS,
+                         "achieved": valu_rate if valu_bound else (achieved_gather if gather_bound else (hbm_measured if hbm_measured is not None else achieved_hbm)),
+                         "achieved_is": "wave64 vector instructions (committed counter pass) / SIMD cycles of this run's launches" if valu_bound else
+                                        ("counted lane accesses / kernel time" if gather_bound else
+                                         ("measured fabric bytes / kernel time (committed counter pass)" if hbm_measured is not None else "algorithmic bytes / kernel time")),
+                         "peak": VALU_MIX_RATE if valu_bound else (peak_gather if gather_bound else HBM_PEAK_GBS),
+                         "unit": "wave64 vector instructions per SIMD cycle" if valu_bound else ("G lane-accesses/s (16 B each)" if gather_bound else "GB/s"),
+                         "frac": min(1.0, valu_rate / VALU_MIX_RATE) if valu_bound else
+                                 (achieved_gather / peak_gather if gather_bound else (hbm_measured if hbm_measured is not None else achieved_hbm) / HBM_PEAK_GBS),
+                         "valu": {"achieved": valu_rate, "peak": VALU_MIX_RATE, "unit": "wave64 vector instructions per SIMD cycle",
+                                  "frac": (valu_rate / VALU_MIX_RATE) if valu_rate is not None else None,
+                                  "cycles_per_instruction": (1.0 / valu_rate) if valu_rate else None,
+                                  "peak_source": "profiles/r3_valu_roof.jsonl: six waves per SIMD sustain one wave64 instruction per 2.5-3.3 cycles "
+                                                 "(v_fma / v_mul / v_add / v_mov / v_and / shifts) or per 4.4-5 (v_cvt, v_min / v_max, v_cmp, v_cndmask, "
+                                                 "v_alignbit, three-operand integer); a traversal step is two thirds of the second kind: one per 4 cycles"},
                          "gather": {"achieved": achieved_gather, "peak": peak_gather, "unit": "G lane-accesses/s (16 B each)", "frac": achieved_gather / peak_gather,
                                     "peak_source": peak_src, "lane_accesses_per_unit": lane_acc[dominant],
                                     "note": "every access counted as a gather; coalesced queue accesses cost a quarter of that"},
