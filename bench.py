@@ -302,7 +302,10 @@ def main():
         valu_rate = None
         if valu and counters.get("avg_launch_ms") and kn[dominant]:
             valu_rate = valu / 2.0 * counters["avg_launch_ms"] / (kms[dominant] / kn[dominant])
-        valu_bound = gather_bound and valu_rate is not None and valu_rate / VALU_MIX_RATE >= achieved_gather / peak_gather
+        # The binding resource is the one the kernel stands closest to: vector issue, or the gather rate (traversal kernels)
+        # / the HBM peak (k_shade) when no counter pass of this workload is committed or the kernel is nearer to those.
+        other_frac = achieved_gather / peak_gather if gather_bound else (hbm_measured if hbm_measured is not None else achieved_hbm) / HBM_PEAK_GBS
+        valu_bound = valu_rate is not None and valu_rate / VALU_MIX_RATE >= other_frac
         out = {
             "metric": "Mrays/s", "value": rays_total / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
@@ -331,7 +334,8 @@ def main():
                          "bound_note": ("vector instruction issue: the SIMDs issue this kernel's instructions at the rate its mix allows "
                                         "(multiply-adds, adds, moves and bit operations 2.5-3.3 cycles per wave64 instruction, conversions, min / max, "
                                         "compares, selects and three-operand integer instructions 4.4-5: tools/valu_roof.hip); its time follows its "
-                                        "instruction count, one for one, and not its loads -- the gather rate under 'gather' is the second limit") if valu_bound else
+                                        "instruction count, one for one, and not its loads -- the second limit is "
+                                        + ("the gather rate under 'gather'" if gather_bound else "the fabric traffic under 'hbm' (measured_frac)")) if valu_bound else
                                        ("per-lane gathers of different addresses: the CU's address/data path takes one lane x 16 B per clock "
                                         "(tools/gather_roof.hip)") if gather_bound else
                                        ("queues streamed once per bounce plus one gathered 128-byte record per hit; algorithmic bytes count what "
@@ -350,7 +354,8 @@ def main():
                                   "cycles_per_instruction": (1.0 / valu_rate) if valu_rate else None,
                                   "peak_source": "profiles/r3_valu_roof.jsonl: six waves per SIMD sustain one wave64 instruction per 2.5-3.3 cycles "
                                                  "(v_fma / v_mul / v_add / v_mov / v_and / shifts) or per 4.4-5 (v_cvt, v_min / v_max, v_cmp, v_cndmask, "
-                                                 "v_alignbit, three-operand integer); a traversal step is two thirds of the second kind: one per 4 cycles"},
+                                                 "v_alignbit, three-operand integer, double precision, the pieces of a division) or per 10 (v_rcp, v_sqrt); "
+                                                 "a traversal step is two thirds of the second kind, the shading code's mix weighs the same: one per 4 cycles"},
                          "gather": {"achieved": achieved_gather, "peak": peak_gather, "unit": "G lane-accesses/s (16 B each)", "frac": achieved_gather / peak_gather,
                                     "peak_source": peak_src, "lane_accesses_per_unit": lane_acc[dominant],
                                     "note": "every access counted as a gather; coalesced queue accesses cost a quarter of that"},
