@@ -10,6 +10,9 @@ pairs = [("%s_bench_%s.json" % (tag, k), "r3_%s_bench_%s.json" % (new, k)) for k
 pairs += [("%s_prof_bench_library_fast.txt" % tag, "r3_%s_rocprof_bench_library_fast.txt" % new),
           ("%s_prof_library_fast.txt" % tag, "r3_%s_rocprof_pmc_library512spp_fast.txt" % new),
           ("%s_prof_veach_fast.txt" % tag, "r3_%s_rocprof_pmc_veach512spp_fast.txt" % new)]
+for a, _ in pairs:
+    if a.endswith(".json") and json.load(open(os.path.join(G, a))).get("rehearsal"):
+        raise SystemExit("%s is the line of a rehearsal run (ranks sharing GPUs): not a measurement, not installed" % a)
 if old != new:
     for f in glob.glob(os.path.join(P, "r3_%s_bench_*.json" % old)) + glob.glob(os.path.join(P, "r3_%s_rocprof_*.txt" % old)):
         os.remove(f)
